@@ -1,0 +1,153 @@
+/*
+ * bce_gpu.h -- C ABI of the MI355X gate-bootstrapping engine (libbce_amd.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of
+ * openfheorg/openfhe-boolean-circuit-evaluator: everything the reference
+ * reaches through `lbcrypto::BinFHEContext` (OpenFHE).  Each entry point cites
+ * the reference interface it replaces (paths relative to the reference root).
+ * Plain C types only; no exception crosses this boundary: every call returns a
+ * bce_status and bce_last_error() holds the message.
+ *
+ * The per-gate call `cc.EvalBinGate(gate, ct1, ct2)` made inside one OpenMP
+ * task per gate (src/circuit.cpp:698-710 -> src/gate.cpp:133,172,200-202)
+ * becomes ONE call bce_eval_gates() for the whole ready-gate frontier; LWE
+ * ciphertexts live in a device-resident pool and are named by slot index
+ * (the reference's `CipherText` alias, src/wire.h:46).
+ */
+#ifndef BCE_GPU_H
+#define BCE_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bce_ctx bce_ctx;
+
+/* lbcrypto::BINFHE_PARAMSET as used at src/utils.cpp:167-172, src/circuit.cpp:69-78
+ * (the reference accepts TOY and STD128_OPT; the rest are OpenFHE's table rows). */
+enum bce_paramset {
+    BCE_TOY = 0, BCE_MEDIUM = 1, BCE_STD128_AP = 2, BCE_STD128_APOPT = 3, BCE_STD128 = 4,
+    BCE_STD128_OPT = 5, BCE_STD192 = 6, BCE_STD192_OPT = 7, BCE_STD256 = 8, BCE_STD256_OPT = 9
+};
+/* lbcrypto::BINFHE_METHOD, src/utils.cpp:180-185 */
+enum bce_method { BCE_AP = 1, BCE_GINX = 2 };
+/* lbcrypto::BINGATE for EvalBinGate (src/gate.cpp:133,172) + the unary ops the driver issues */
+enum bce_op {
+    BCE_OR = 0, BCE_AND = 1, BCE_NOR = 2, BCE_NAND = 3, BCE_XOR_FAST = 4, BCE_XNOR_FAST = 5,
+    BCE_OP_NOT = 16,     /* EvalNOT, src/gate.cpp:112,198-199 : no bootstrap      */
+    BCE_OP_REFRESH = 17, /* Bootstrap(ct) as run by Encrypt(BOOTSTRAPPED)         */
+    BCE_OP_COPY = 18     /* OUTPUT gate copy, src/gate.cpp:90-94                  */
+};
+enum bce_status {
+    BCE_OK = 0, BCE_ERR_ARG = 1, BCE_ERR_NO_DEVICE = 2, BCE_ERR_HIP = 3, BCE_ERR_NO_KEYS = 4,
+    BCE_ERR_POOL = 5, BCE_ERR_UNSUPPORTED = 6, BCE_ERR_STATE = 7
+};
+/* lbcrypto::BINFHE_OUTPUT of BinFHEContext::Encrypt (v1.0.x default is BOOTSTRAPPED) */
+enum bce_encrypt_mode { BCE_FRESH = 0, BCE_BOOTSTRAPPED = 1 };
+
+/* parameter block (all u64), same order as the oracle's */
+enum { BCE_P_n = 0, BCE_P_N, BCE_P_q, BCE_P_Q, BCE_P_qKS, BCE_P_baseKS, BCE_P_dKS, BCE_P_baseG, BCE_P_dG,
+       BCE_P_baseR, BCE_P_dR, BCE_P_method, BCE_P_psi, BCE_P_COUNT };
+
+/* One gate of the frontier.  `neg0/neg1` fold EvalNOT of an input into the
+ * bootstrap's LWE prep, which is how XOR = (a AND !b) OR (!a AND b)
+ * (src/gate.cpp:198-202) is issued without materialising the NOTs. */
+typedef struct bce_gate_desc {
+    uint32_t op;   /* enum bce_op */
+    uint32_t in0;  /* pool slot */
+    uint32_t in1;  /* pool slot (ignored by 1-input ops) */
+    uint32_t out;  /* pool slot */
+    uint32_t neg0;
+    uint32_t neg1;
+} bce_gate_desc;
+
+/* cumulative device timing, measured with HIP events on the engine's stream */
+typedef struct bce_timing {
+    double   blind_rotate_ms;   /* sum over launches of the blind-rotation kernel */
+    double   tail_ms;           /* extract + modswitch + keyswitch + modswitch    */
+    uint64_t blind_rotate_launches;
+    uint64_t bootstraps;        /* gate-bootstraps executed (NOT/COPY not counted) */
+} bce_timing;
+
+/* ---- context ----------------------------------------------------------- */
+/* BinFHEContext() + GenerateBinFHEContext(set, method): src/circuit.cpp:65,88.
+ * device = HIP device ordinal.  Fails with BCE_ERR_NO_DEVICE when no GPU is
+ * visible: there is no CPU fallback in the product. */
+int bce_ctx_create(int paramset, int method, int device, bce_ctx** out);
+int bce_ctx_create_custom(uint32_t n, uint32_t N, uint64_t q, uint64_t Q, uint64_t qKS, uint32_t baseKS,
+                          uint32_t baseG, uint32_t baseR, int method, int device, bce_ctx** out);
+void bce_ctx_destroy(bce_ctx*);
+/* message of the last failing call on this ctx (ctx may be NULL: last create failure) */
+const char* bce_last_error(const bce_ctx*);
+int bce_get_params(const bce_ctx*, uint64_t out[BCE_P_COUNT]);
+
+/* ---- keys -------------------------------------------------------------- */
+/* sk = cc.KeyGen(); cc.BTKeyGen(sk): src/circuit.cpp:90-91.  Deterministic from
+ * a 32-byte seed (ChaCha20 streams, DESIGN.md "PRNG spec"); RGSW rows are
+ * transformed and multiplied by the ring key on the device. */
+int bce_keygen(bce_ctx*, const uint8_t seed[32]);
+/* canonical exchange format = coefficient domain, u64 words (what an OpenFHE
+ * export would be converted to): s[n], z[N] in {-1,0,1}; bsk [i][key][row][col][N]
+ * (GINX) or [i][v][k][row][col][N] (AP); ksk [i][v][j][n+1] mod qKS. */
+int bce_import_keys(bce_ctx*, const int32_t* s, const int32_t* z, const uint64_t* bsk, uint64_t bsk_words,
+                    const uint32_t* ksk, uint64_t ksk_words);
+uint64_t bce_bsk_words(const bce_ctx*);
+uint64_t bce_ksk_words(const bce_ctx*);
+int bce_export_sk(const bce_ctx*, int32_t* s, int32_t* z);
+int bce_export_bsk(bce_ctx*, uint64_t* bsk);
+int bce_export_ksk(bce_ctx*, uint32_t* ksk);
+
+/* ---- device LWE pool --------------------------------------------------- */
+/* LWECiphertext objects (src/wire.h:46, src/gate.h:75-78) become slots. */
+int bce_pool_reserve(bce_ctx*, uint32_t slots);
+uint32_t bce_pool_slots(const bce_ctx*);
+/* ciphertext = u64[n+1] (a[0..n), b), the reference's NativeInteger layout */
+int bce_lwe_write(bce_ctx*, const uint32_t* slots, uint32_t count, const uint64_t* cts);
+int bce_lwe_read(bce_ctx*, const uint32_t* slots, uint32_t count, uint64_t* cts);
+
+/* cc.Encrypt(sk, bit): src/circuit.cpp:506, src/gate.cpp:118,139,143,158,179,211.
+ * Ciphertext k uses PRNG stream enc_index_base + k.  BCE_BOOTSTRAPPED also runs
+ * Bootstrap(ct) on the device as OpenFHE v1.0.x does by default. */
+int bce_encrypt_bits(bce_ctx*, const uint8_t* bits, const uint32_t* slots, uint32_t count,
+                     uint64_t enc_index_base, int mode);
+/* cc.Decrypt(sk, ct, &res): src/circuit.cpp:800, src/gate.cpp:72,97,115,... (res in 0..3) */
+int bce_decrypt_bits(bce_ctx*, const uint32_t* slots, uint32_t count, uint8_t* bits);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* Batched EvalBinGate / EvalNOT over one ready frontier:
+ * src/circuit.cpp:698-710 + src/gate.cpp:112,133,146,172,198-202.
+ * All descriptors of one call are independent (no `out` is an input of the
+ * same call).  Asynchronous on the engine's stream; results are ordered with
+ * later calls; bce_synchronize() waits. */
+int bce_eval_gates(bce_ctx*, uint32_t n_desc, const bce_gate_desc* descs);
+/* Same frontier applied to `instances` independent input sets laid out
+ * `slot_stride` slots apart (lock-step evaluation of K circuit instances,
+ * the reference's sequential numTestLoops loop, src/test_aes.cpp:179-182). */
+int bce_eval_gates_strided(bce_ctx*, uint32_t n_desc, const bce_gate_desc* descs, uint32_t instances,
+                           uint32_t slot_stride);
+int bce_synchronize(bce_ctx*);
+
+/* ---- measurement ------------------------------------------------------- */
+int bce_timing_reset(bce_ctx*);
+int bce_timing_get(bce_ctx*, bce_timing* out); /* synchronizes */
+/* algorithmic bytes one gate-bootstrap reads at the widths this engine ships
+ * (SURVEY.md 8(d) formula with w_bsk, w_ks, w_ct of this build) */
+uint64_t bce_bytes_per_bootstrap(const bce_ctx*);
+
+/* ---- staged outputs for parity tests ----------------------------------- */
+/* Runs the frontier like bce_eval_gates and also returns the intermediates
+ * (any pointer may be NULL): acc = accumulator after blind rotation,
+ * COEFFICIENT domain, u64 [n_desc][2][N]; lweN = after extract + ModSwitch(Q->qKS),
+ * u64 [n_desc][N+1]; ks = after KeySwitch, u64 [n_desc][n+1].  Bootstrapped ops only. */
+int bce_debug_eval_stages(bce_ctx*, uint32_t n_desc, const bce_gate_desc* descs, uint64_t* acc,
+                          uint64_t* lweN, uint64_t* ks);
+/* forward (inverse=0) / inverse negacyclic NTT of `count` polys, in place, u64 [count][N];
+ * forward output is in the engine's internal evaluation order. */
+int bce_debug_ntt(bce_ctx*, uint64_t* polys, uint32_t count, int inverse);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,751 @@
+// engine.cpp -- host side of the C ABI in include/bce_gpu.h.
+//
+// Replaces what the reference obtains from lbcrypto::BinFHEContext (OpenFHE):
+// GenerateBinFHEContext / KeyGen / BTKeyGen (src/circuit.cpp:88-91), Encrypt / Decrypt
+// (src/circuit.cpp:506,800) and the per-gate EvalBinGate / EvalNOT calls
+// (src/gate.cpp:112,133,172,198-202), the latter batched per ready frontier.
+// There is no CPU compute path here: without a HIP device every call fails loudly.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/bce_gpu.h"
+#include "host_math.hpp"
+#include "kernels.hpp"
+#include "prng.hpp"
+
+using namespace bce;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ParamRow { u32 bits, cyclo, n; u64 q, qKS; u32 baseKS, baseG, baseR; };
+// OpenFHE v1.0.x GenerateBinFHEContext table: {numberBits, cyclOrder, latticeParam, mod, modKS(0 = PRIME), baseKS, gadgetBase, baseRK}
+const ParamRow kParamTable[] = {
+    {27, 1024, 64, 512, 0, 25, 1u << 9, 23},              // TOY
+    {28, 2048, 422, 1024, 1u << 14, 1u << 7, 1u << 10, 32},  // MEDIUM
+    {27, 2048, 512, 1024, 1u << 14, 1u << 7, 1u << 9, 32},   // STD128_AP
+    {27, 2048, 502, 1024, 1u << 14, 1u << 7, 1u << 9, 32},   // STD128_APOPT
+    {27, 2048, 512, 1024, 1u << 14, 1u << 7, 1u << 7, 32},   // STD128
+    {27, 2048, 502, 1024, 1u << 14, 1u << 7, 1u << 7, 32},   // STD128_OPT
+    {37, 4096, 1024, 1024, 1u << 19, 28, 1u << 13, 32},      // STD192
+    {37, 4096, 805, 1024, 1u << 15, 32, 1u << 13, 32},       // STD192_OPT
+    {29, 4096, 1024, 2048, 1u << 14, 1u << 7, 1u << 8, 46},  // STD256
+    {29, 4096, 990, 2048, 1u << 14, 1u << 7, 1u << 8, 46},   // STD256_OPT
+};
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+}  // namespace
+
+struct bce_ctx {
+    // parameters
+    u32 n = 0, N = 0, logN = 0;
+    u64 q = 0, Q = 0, qKS = 0, psi = 0;
+    u32 baseKS = 0, dKS = 0, baseG = 0, gBits = 0, dG = 0, baseR = 0, dR = 0;
+    int method = 0, device = 0;
+    std::string err;
+
+    hipStream_t stream = nullptr;
+    DevParams P{};
+    // device tables / keys
+    uint2 *d_twf = nullptr, *d_twi = nullptr;
+    u32* d_bsk = nullptr;
+    void* d_ksk = nullptr;
+    u64 bsk_polys = 0;
+    bool have_keys = false;
+    // host secrets
+    std::vector<int32_t> s, z;
+    uint8_t seed[32] = {0};
+    // pool
+    u32* d_pool = nullptr;
+    u32 pool_slots = 0;
+    // work buffers
+    u32* d_acc = nullptr;
+    size_t acc_cap = 0;  // bootstraps
+    static constexpr int kRing = 4;
+    bce_gate_desc* d_descs[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    bce_gate_desc* h_descs[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    size_t desc_cap[kRing] = {0, 0, 0, 0};
+    hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
+    bool ring_busy[kRing] = {false, false, false, false};
+    int ring_pos = 0;
+    // timing
+    std::vector<EventPair> pending, free_events;
+    bce_timing timing{};
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIP_TRY(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) return (ctx)->fail(BCE_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 baseR, int method, int device,
+              bce_ctx** out) {
+    if (!out) return BCE_ERR_ARG;
+    *out = nullptr;
+    if (method != BCE_AP && method != BCE_GINX) { g_create_error = "bad method (expect AP=1 or GINX=2)"; return BCE_ERR_ARG; }
+    if (N < 512 || N > 2048 || (N & (N - 1))) { g_create_error = "ring dimension N must be 512, 1024 or 2048"; return BCE_ERR_UNSUPPORTED; }
+    if ((q & (q - 1)) || q > 2 * (u64)N || q < 8) { g_create_error = "LWE modulus q must be a power of two dividing 2N"; return BCE_ERR_ARG; }
+    if (!is_prime_u64(Q) || (Q - 1) % (2ull * N)) { g_create_error = "Q must be a prime = 1 mod 2N"; return BCE_ERR_ARG; }
+    if (Q >= (1ull << 28)) { g_create_error = "ring modulus Q >= 2^28 needs the 64-bit kernels (not built in this round)"; return BCE_ERR_UNSUPPORTED; }
+    if (baseG & (baseG - 1)) { g_create_error = "gadget base must be a power of two"; return BCE_ERR_ARG; }
+    if (method == BCE_AP) { g_create_error = "AP (DM) blind rotation is not built in this round"; return BCE_ERR_UNSUPPORTED; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_error = "no HIP device visible: the engine has no CPU fallback";
+        return BCE_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { g_create_error = "bad device ordinal"; return BCE_ERR_ARG; }
+
+    std::unique_ptr<bce_ctx> c(new bce_ctx);
+    c->n = n; c->N = N; c->q = q; c->Q = Q; c->qKS = qKS ? qKS : Q;
+    c->baseKS = baseKS; c->baseG = baseG; c->baseR = baseR; c->method = method; c->device = device;
+    while ((1u << c->logN) < N) ++c->logN;
+    while ((1u << c->gBits) < baseG) ++c->gBits;
+    c->dKS = digit_count((double)c->qKS, (double)baseKS);
+    c->dG = digit_count((double)Q, (double)baseG);
+    c->dR = digit_count((double)q, (double)baseR);
+    if (2 * c->dG > 8) { g_create_error = "more than 8 RGSW rows per ciphertext is not supported"; return BCE_ERR_UNSUPPORTED; }
+    if (c->qKS > 0xFFFFFFFFull) { g_create_error = "qKS must fit 32 bits"; return BCE_ERR_UNSUPPORTED; }
+    c->psi = min_primitive_root(Q, 2ull * N);
+
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return BCE_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; return BCE_ERR_HIP; }
+
+    // twiddle tables, OpenFHE ordering: tw[brv(i)] = psi^i
+    std::vector<uint2> twf(N), twi(N);
+    u64 ipsi = pow_mod(c->psi, Q - 2, Q), p = 1, ip = 1;
+    for (u32 i = 0; i < N; ++i) {
+        u32 r = bit_reverse(i, (int)c->logN);
+        twf[r] = make_uint2((u32)p, (u32)(((u128)p << 32) / Q));
+        twi[r] = make_uint2((u32)ip, (u32)(((u128)ip << 32) / Q));
+        p = mul_mod(p, c->psi, Q);
+        ip = mul_mod(ip, ipsi, Q);
+    }
+    if (hipMalloc(&c->d_twf, sizeof(uint2) * N) != hipSuccess || hipMalloc(&c->d_twi, sizeof(uint2) * N) != hipSuccess) {
+        g_create_error = "hipMalloc(twiddles) failed";
+        return BCE_ERR_HIP;
+    }
+    hipMemcpy(c->d_twf, twf.data(), sizeof(uint2) * N, hipMemcpyHostToDevice);
+    hipMemcpy(c->d_twi, twi.data(), sizeof(uint2) * N, hipMemcpyHostToDevice);
+    for (int i = 0; i < bce_ctx::kRing; ++i) hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming);
+
+    DevParams& P = c->P;
+    P.n = n; P.N = N; P.logN = c->logN; P.q = (u32)q; P.Q = (u32)Q; P.qKS = (u32)c->qKS;
+    P.baseKS = baseKS; P.dKS = c->dKS;
+    P.ksk_stride = (n + 1 + 63) & ~63u;
+    P.ksk_u16 = c->qKS <= 65536 ? 1 : 0;
+    P.gBits = c->gBits; P.dG = c->dG; P.baseR = baseR; P.dR = c->dR;
+    P.factor = (u32)(2 * N / q);
+    P.Q8p1 = (u32)(Q / 8 + 1);
+    int bq = bit_length(Q);
+    P.red_shift = (u32)std::max(2 * bq + 3 - 32, 0);
+    P.red_mu = (u32)((((u128)1) << (32 + P.red_shift)) / Q);
+    u64 ninv = pow_mod(N, Q - 2, Q);
+    P.Ninv = (u32)ninv;
+    P.Ninv_s = (u32)(((u128)ninv << 32) / Q);
+    P.tw_f = c->d_twf; P.tw_i = c->d_twi;
+    P.pool_stride = n + 1;
+    *out = c.release();
+    return BCE_OK;
+}
+
+u64 rgsw_rows_total(const bce_ctx* c) {
+    const u64 R = 2ull * c->dG;
+    return c->method == BCE_GINX ? (u64)c->n * 2 * R : (u64)c->n * c->baseR * c->dR * R;
+}
+
+int alloc_keys(bce_ctx* c) {
+    if (!c->d_bsk) {
+        c->bsk_polys = rgsw_rows_total(c) * 2;
+        HIP_TRY(c, hipMalloc(&c->d_bsk, sizeof(u32) * c->bsk_polys * c->N));
+    }
+    if (!c->d_ksk) {
+        size_t rows = (size_t)c->N * c->baseKS * c->dKS;
+        HIP_TRY(c, hipMalloc(&c->d_ksk, rows * c->P.ksk_stride * (c->P.ksk_u16 ? 2 : 4)));
+    }
+    c->P.bsk = c->d_bsk;
+    c->P.ksk = c->d_ksk;
+    return BCE_OK;
+}
+
+// host KSK rows (u32, canonical [row][n+1]) -> padded device layout
+int upload_ksk(bce_ctx* c, const u32* ksk) {
+    const size_t rows = (size_t)c->N * c->baseKS * c->dKS, W = c->n + 1, S = c->P.ksk_stride;
+    if (c->P.ksk_u16) {
+        std::vector<uint16_t> buf(rows * S, 0);
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t k = 0; k < W; ++k) buf[r * S + k] = (uint16_t)ksk[r * W + k];
+        HIP_TRY(c, hipMemcpy(c->d_ksk, buf.data(), buf.size() * 2, hipMemcpyHostToDevice));
+    } else {
+        std::vector<u32> buf(rows * S, 0);
+        for (size_t r = 0; r < rows; ++r) std::memcpy(&buf[r * S], &ksk[r * W], W * 4);
+        HIP_TRY(c, hipMemcpy(c->d_ksk, buf.data(), buf.size() * 4, hipMemcpyHostToDevice));
+    }
+    return BCE_OK;
+}
+
+template <typename F>
+void parallel_for(size_t count, F fn) {
+    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (count < 2 * nt) nt = 1;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([=]() {
+            for (size_t i = t; i < count; i += nt) fn(i);
+        });
+    for (auto& x : th) x.join();
+}
+
+int ensure_acc(bce_ctx* c, size_t boots) {
+    if (boots <= c->acc_cap) return BCE_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_acc) hipFree(c->d_acc);
+    c->d_acc = nullptr;
+    size_t cap = std::max(boots, c->acc_cap * 2);
+    HIP_TRY(c, hipMalloc(&c->d_acc, cap * 2 * c->N * sizeof(u32)));
+    c->acc_cap = cap;
+    return BCE_OK;
+}
+
+// stage a descriptor list into the next ring slot; returns device pointer
+int stage_descs(bce_ctx* c, const bce_gate_desc* d, size_t n, bce_gate_desc** dev, int* slot) {
+    int k = c->ring_pos;
+    c->ring_pos = (k + 1) % bce_ctx::kRing;
+    if (c->ring_busy[k]) {
+        HIP_TRY(c, hipEventSynchronize(c->ring_ev[k]));
+        c->ring_busy[k] = false;
+    }
+    if (n > c->desc_cap[k]) {
+        if (c->d_descs[k]) hipFree(c->d_descs[k]);
+        if (c->h_descs[k]) hipHostFree(c->h_descs[k]);
+        size_t cap = std::max(n, (size_t)1024);
+        HIP_TRY(c, hipMalloc(&c->d_descs[k], cap * sizeof(bce_gate_desc)));
+        HIP_TRY(c, hipHostMalloc(&c->h_descs[k], cap * sizeof(bce_gate_desc)));
+        c->desc_cap[k] = cap;
+    }
+    std::memcpy(c->h_descs[k], d, n * sizeof(bce_gate_desc));
+    HIP_TRY(c, hipMemcpyAsync(c->d_descs[k], c->h_descs[k], n * sizeof(bce_gate_desc), hipMemcpyHostToDevice, c->stream));
+    *dev = c->d_descs[k];
+    *slot = k;
+    return BCE_OK;
+}
+
+EventPair get_events(bce_ctx* c, int kind) {
+    EventPair p;
+    if (!c->free_events.empty()) {
+        p = c->free_events.back();
+        c->free_events.pop_back();
+    } else {
+        hipEventCreate(&p.a);
+        hipEventCreate(&p.b);
+    }
+    p.kind = kind;
+    return p;
+}
+
+void drain_timing(bce_ctx* c) {
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            if (p.kind == 0) c->timing.blind_rotate_ms += ms; else c->timing.tail_ms += ms;
+        }
+        c->free_events.push_back(p);
+    }
+    c->pending.clear();
+}
+
+int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances, u32 slot_stride, u64* dbg_acc,
+              u64* dbg_lweN, u64* dbg_ks) {
+    if (n_desc == 0 || instances == 0) return BCE_OK;
+    if (!descs) return c->fail(BCE_ERR_ARG, "null descriptor list");
+    if (!c->have_keys) return c->fail(BCE_ERR_NO_KEYS, "bce_keygen / bce_import_keys has not been called");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<bce_gate_desc> boot, unary;
+    boot.reserve(n_desc);
+    const u64 max_slot = (u64)(instances - 1) * slot_stride;
+    for (u32 i = 0; i < n_desc; ++i) {
+        const bce_gate_desc& g = descs[i];
+        const bool is_boot = g.op <= BCE_XNOR_FAST || g.op == BCE_OP_REFRESH;
+        const bool is_unary = g.op == BCE_OP_NOT || g.op == BCE_OP_COPY;
+        if (!is_boot && !is_unary) return c->fail(BCE_ERR_ARG, "descriptor %u: unknown op %u", i, g.op);
+        u64 hi = std::max<u64>(g.in0, g.out);
+        if (g.op <= BCE_XNOR_FAST) hi = std::max<u64>(hi, g.in1);
+        if (hi + max_slot >= c->pool_slots) return c->fail(BCE_ERR_POOL, "descriptor %u: slot %llu outside the pool (%u slots)", i, (unsigned long long)(hi + max_slot), c->pool_slots);
+        (is_boot ? boot : unary).push_back(g);
+    }
+    if (!boot.empty()) {
+        const size_t nb = boot.size() * (size_t)instances;
+        int rc = ensure_acc(c, nb);
+        if (rc) return rc;
+        bce_gate_desc* dd = nullptr;
+        int slot = 0;
+        rc = stage_descs(c, boot.data(), boot.size(), &dd, &slot);
+        if (rc) return rc;
+        EventPair e0 = get_events(c, 0);
+        hipEventRecord(e0.a, c->stream);
+        HIP_TRY(c, launch_blind_rotate(c->P, dd, (u32)boot.size(), instances, slot_stride, c->d_acc, c->stream));
+        hipEventRecord(e0.b, c->stream);
+        c->pending.push_back(e0);
+        u32 *d_lweN = nullptr, *d_ks = nullptr;
+        if (dbg_lweN) HIP_TRY(c, hipMalloc(&d_lweN, nb * (c->N + 1) * sizeof(u32)));
+        if (dbg_ks) HIP_TRY(c, hipMalloc(&d_ks, nb * (c->n + 1) * sizeof(u32)));
+        EventPair e1 = get_events(c, 1);
+        hipEventRecord(e1.a, c->stream);
+        HIP_TRY(c, launch_tail(c->P, dd, (u32)boot.size(), instances, slot_stride, c->d_acc, d_lweN, d_ks, c->stream));
+        hipEventRecord(e1.b, c->stream);
+        c->pending.push_back(e1);
+        hipEventRecord(c->ring_ev[slot], c->stream);
+        c->ring_busy[slot] = true;
+        c->timing.blind_rotate_launches += 1;
+        c->timing.bootstraps += nb;
+        if (dbg_acc || dbg_lweN || dbg_ks) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            std::vector<u32> tmp;
+            auto fetch = [&](const u32* dev, size_t words, u64* dst) -> int {
+                tmp.resize(words);
+                HIP_TRY(c, hipMemcpy(tmp.data(), dev, words * 4, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < words; ++i) dst[i] = tmp[i];
+                return BCE_OK;
+            };
+            if (dbg_acc && (rc = fetch(c->d_acc, nb * 2 * c->N, dbg_acc))) return rc;
+            if (dbg_lweN && (rc = fetch(d_lweN, nb * (c->N + 1), dbg_lweN))) return rc;
+            if (dbg_ks && (rc = fetch(d_ks, nb * (c->n + 1), dbg_ks))) return rc;
+            if (d_lweN) hipFree(d_lweN);
+            if (d_ks) hipFree(d_ks);
+        }
+        if (c->pending.size() > 4096) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            drain_timing(c);
+        }
+    }
+    if (!unary.empty()) {
+        bce_gate_desc* dd = nullptr;
+        int slot = 0;
+        int rc = stage_descs(c, unary.data(), unary.size(), &dd, &slot);
+        if (rc) return rc;
+        HIP_TRY(c, launch_lwe_unary(c->P, dd, (u32)unary.size(), instances, slot_stride, c->stream));
+        hipEventRecord(c->ring_ev[slot], c->stream);
+        c->ring_busy[slot] = true;
+    }
+    return BCE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bce_ctx_create(int paramset, int method, int device, bce_ctx** out) {
+    if (paramset < 0 || paramset > BCE_STD256_OPT) { g_create_error = "unknown parameter set"; if (out) *out = nullptr; return BCE_ERR_ARG; }
+    const ParamRow& r = kParamTable[paramset];
+    const u64 Q = previous_prime(first_prime(r.bits, r.cyclo), r.cyclo);
+    return build_ctx(r.n, r.cyclo / 2, r.q, Q, r.qKS, r.baseKS, r.baseG, r.baseR, method, device, out);
+}
+
+int bce_ctx_create_custom(uint32_t n, uint32_t N, uint64_t q, uint64_t Q, uint64_t qKS, uint32_t baseKS, uint32_t baseG,
+                          uint32_t baseR, int method, int device, bce_ctx** out) {
+    return build_ctx(n, N, q, Q, qKS, baseKS, baseG, baseR, method, device, out);
+}
+
+void bce_ctx_destroy(bce_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    drain_timing(c);
+    for (auto& p : c->free_events) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (int i = 0; i < bce_ctx::kRing; ++i) {
+        if (c->d_descs[i]) hipFree(c->d_descs[i]);
+        if (c->h_descs[i]) hipHostFree(c->h_descs[i]);
+        if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
+    }
+    hipFree(c->d_twf); hipFree(c->d_twi); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* bce_last_error(const bce_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int bce_get_params(const bce_ctx* c, uint64_t out[BCE_P_COUNT]) {
+    if (!c || !out) return BCE_ERR_ARG;
+    out[BCE_P_n] = c->n; out[BCE_P_N] = c->N; out[BCE_P_q] = c->q; out[BCE_P_Q] = c->Q; out[BCE_P_qKS] = c->qKS;
+    out[BCE_P_baseKS] = c->baseKS; out[BCE_P_dKS] = c->dKS; out[BCE_P_baseG] = c->baseG; out[BCE_P_dG] = c->dG;
+    out[BCE_P_baseR] = c->baseR; out[BCE_P_dR] = c->dR; out[BCE_P_method] = (u64)c->method; out[BCE_P_psi] = c->psi;
+    return BCE_OK;
+}
+
+uint64_t bce_bsk_words(const bce_ctx* c) { return c ? rgsw_rows_total(c) * 2 * c->N : 0; }
+uint64_t bce_ksk_words(const bce_ctx* c) { return c ? (u64)c->N * c->baseKS * c->dKS * (c->n + 1) : 0; }
+
+int bce_keygen(bce_ctx* c, const uint8_t seed[32]) {
+    if (!c || !seed) return BCE_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = alloc_keys(c);
+    if (rc) return rc;
+    std::memcpy(c->seed, seed, 32);
+    const u32 n = c->n, N = c->N;
+    const u64 Q = c->Q, qKS = c->qKS;
+    const GaussSampler gauss(3.19);
+    c->s.resize(n);
+    c->z.resize(N);
+    { ChaChaStream st(seed, kDomSK, 0); for (u32 i = 0; i < n; ++i) c->s[i] = draw_ternary(st); }
+    { ChaChaStream st(seed, kDomZ, 0); for (u32 i = 0; i < N; ++i) c->z[i] = draw_ternary(st); }
+
+    // LWE key-switching key: K[i][v][j] = LWE_s(z_i * v * baseKS^j) mod qKS
+    {
+        const u32 B = c->baseKS, D = c->dKS;
+        const size_t W = n + 1;
+        std::vector<u32> ksk((size_t)N * B * D * W);
+        std::vector<u64> pw(D);
+        { u64 v = 1; for (u32 j = 0; j < D; ++j) { pw[j] = v; v *= B; } }
+        const int32_t* s = c->s.data();
+        const int32_t* z = c->z.data();
+        u32* kp = ksk.data();
+        const u64* pwp = pw.data();
+        const uint8_t* sd = c->seed;
+        parallel_for(N, [=, &gauss](size_t i) {
+            const u64 zi = lift_signed(z[i], qKS);
+            for (u32 v = 0; v < B; ++v)
+                for (u32 j = 0; j < D; ++j) {
+                    const u64 idx = ((u64)i * B + v) * D + j;
+                    ChaChaStream st(sd, kDomKSK, idx);
+                    u32* row = kp + idx * W;
+                    u128 acc = 0;
+                    for (u32 k = 0; k < n; ++k) {
+                        u64 a = draw_uniform(st, qKS);
+                        row[k] = (u32)a;
+                        acc += (u128)a * lift_signed(s[k], qKS);
+                    }
+                    u64 e = lift_signed(gauss.draw(st), qKS);
+                    u64 msg = (u64)((u128)zi * (u64)((u128)v * pwp[j] % qKS) % qKS);
+                    row[n] = (u32)((acc + e + msg) % qKS);
+                }
+        });
+        rc = upload_ksk(c, ksk.data());
+        if (rc) return rc;
+    }
+
+    // Bootstrapping key (GINX): ek[i][0] = RGSW(s_i == 1), ek[i][1] = RGSW(s_i == -1).
+    // Host draws (a, e) per row and adds the gadget; the device does the NTTs and a*z.
+    {
+        const u32 R = 2 * c->dG;
+        const u64 rows = rgsw_rows_total(c);
+        std::vector<u32> bsk(rows * 2 * N), ta(rows * N);
+        std::vector<u64> gpow(c->dG);
+        { u64 v = 1; for (u32 i = 0; i < c->dG; ++i) { gpow[i] = v; v = mul_mod(v, c->baseG, Q); } }
+        u32* bp = bsk.data();
+        u32* tp = ta.data();
+        const u64* gp = gpow.data();
+        const int32_t* s = c->s.data();
+        const uint8_t* sd = c->seed;
+        parallel_for(rows, [=, &gauss](size_t rowid) {
+            const u32 r = (u32)(rowid % R);
+            const u64 ek = rowid / R;            // i*2 + key
+            const u32 i = (u32)(ek / 2), key = (u32)(ek % 2);
+            const bool one = key == 0 ? (s[i] == 1) : (s[i] == -1);
+            ChaChaStream st(sd, kDomBSK, rowid);
+            u32* a = bp + (rowid * 2 + 0) * N;
+            u32* b = bp + (rowid * 2 + 1) * N;
+            u32* t = tp + rowid * N;
+            for (u32 k = 0; k < N; ++k) t[k] = a[k] = (u32)draw_uniform(st, Q);
+            for (u32 k = 0; k < N; ++k) b[k] = (u32)lift_signed(gauss.draw(st), Q);
+            if (one) {
+                u32* tgt = (r & 1) ? b : a;      // row 2j: column 0, row 2j+1: column 1
+                tgt[0] = (u32)((tgt[0] + gp[r >> 1]) % Q);
+            }
+        });
+        std::vector<u32> zq(N);
+        for (u32 k = 0; k < N; ++k) zq[k] = (u32)lift_signed(c->z[k], Q);
+        u32 *d_ta = nullptr, *d_z = nullptr;
+        HIP_TRY(c, hipMalloc(&d_ta, ta.size() * 4));
+        HIP_TRY(c, hipMalloc(&d_z, N * 4));
+        HIP_TRY(c, hipMemcpy(c->d_bsk, bsk.data(), bsk.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_ta, ta.data(), ta.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_z, zq.data(), N * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, launch_ntt_batch(c->P, c->d_bsk, (u32)(rows * 2), 0, c->stream));
+        HIP_TRY(c, launch_ntt_batch(c->P, d_ta, (u32)rows, 0, c->stream));
+        HIP_TRY(c, launch_ntt_batch(c->P, d_z, 1, 0, c->stream));
+        // b-column (odd polys) += NTT(a) * NTT(z)
+        HIP_TRY(c, launch_pointwise_mac(c->P, c->d_bsk + N, d_ta, d_z, (u32)rows, 2, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipFree(d_ta);
+        hipFree(d_z);
+    }
+    c->have_keys = true;
+    return BCE_OK;
+}
+
+int bce_import_keys(bce_ctx* c, const int32_t* s, const int32_t* z, const uint64_t* bsk, uint64_t bsk_words,
+                    const uint32_t* ksk, uint64_t ksk_words) {
+    if (!c || !s || !bsk || !ksk) return c ? c->fail(BCE_ERR_ARG, "null key pointer") : BCE_ERR_ARG;
+    if (bsk_words != bce_bsk_words(c) || ksk_words != bce_ksk_words(c)) return c->fail(BCE_ERR_ARG, "key sizes do not match the parameter set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = alloc_keys(c);
+    if (rc) return rc;
+    c->s.assign(s, s + c->n);
+    if (z) c->z.assign(z, z + c->N); else c->z.clear();
+    std::vector<u32> tmp(bsk_words);
+    for (u64 i = 0; i < bsk_words; ++i) {
+        if (bsk[i] >= c->Q) return c->fail(BCE_ERR_ARG, "bsk word %llu not reduced mod Q", (unsigned long long)i);
+        tmp[i] = (u32)bsk[i];
+    }
+    HIP_TRY(c, hipMemcpy(c->d_bsk, tmp.data(), bsk_words * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, launch_ntt_batch(c->P, c->d_bsk, (u32)(bsk_words / c->N), 0, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc = upload_ksk(c, ksk);
+    if (rc) return rc;
+    c->have_keys = true;
+    return BCE_OK;
+}
+
+int bce_export_sk(const bce_ctx* c, int32_t* s, int32_t* z) {
+    if (!c || !c->have_keys) return BCE_ERR_NO_KEYS;
+    if (s) std::memcpy(s, c->s.data(), c->n * sizeof(int32_t));
+    if (z && !c->z.empty()) std::memcpy(z, c->z.data(), c->N * sizeof(int32_t));
+    return BCE_OK;
+}
+
+int bce_export_bsk(bce_ctx* c, uint64_t* bsk) {
+    if (!c || !bsk) return BCE_ERR_ARG;
+    if (!c->have_keys) return c->fail(BCE_ERR_NO_KEYS, "no keys");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const u64 words = bce_bsk_words(c);
+    u32* d_tmp = nullptr;
+    HIP_TRY(c, hipMalloc(&d_tmp, words * 4));
+    HIP_TRY(c, hipMemcpyAsync(d_tmp, c->d_bsk, words * 4, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, launch_ntt_batch(c->P, d_tmp, (u32)(words / c->N), 1, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<u32> tmp(words);
+    HIP_TRY(c, hipMemcpy(tmp.data(), d_tmp, words * 4, hipMemcpyDeviceToHost));
+    hipFree(d_tmp);
+    for (u64 i = 0; i < words; ++i) bsk[i] = tmp[i];
+    return BCE_OK;
+}
+
+int bce_export_ksk(bce_ctx* c, uint32_t* ksk) {
+    if (!c || !ksk) return BCE_ERR_ARG;
+    if (!c->have_keys) return c->fail(BCE_ERR_NO_KEYS, "no keys");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t rows = (size_t)c->N * c->baseKS * c->dKS, W = c->n + 1, S = c->P.ksk_stride;
+    if (c->P.ksk_u16) {
+        std::vector<uint16_t> buf(rows * S);
+        HIP_TRY(c, hipMemcpy(buf.data(), c->d_ksk, buf.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t k = 0; k < W; ++k) ksk[r * W + k] = buf[r * S + k];
+    } else {
+        std::vector<u32> buf(rows * S);
+        HIP_TRY(c, hipMemcpy(buf.data(), c->d_ksk, buf.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < rows; ++r) std::memcpy(&ksk[r * W], &buf[r * S], W * 4);
+    }
+    return BCE_OK;
+}
+
+int bce_pool_reserve(bce_ctx* c, uint32_t slots) {
+    if (!c) return BCE_ERR_ARG;
+    if (slots <= c->pool_slots) return BCE_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    u32* np = nullptr;
+    HIP_TRY(c, hipMalloc(&np, (size_t)slots * c->P.pool_stride * 4));
+    HIP_TRY(c, hipMemset(np, 0, (size_t)slots * c->P.pool_stride * 4));
+    if (c->d_pool) {
+        HIP_TRY(c, hipMemcpy(np, c->d_pool, (size_t)c->pool_slots * c->P.pool_stride * 4, hipMemcpyDeviceToDevice));
+        hipFree(c->d_pool);
+    }
+    c->d_pool = np;
+    c->pool_slots = slots;
+    c->P.pool = np;
+    return BCE_OK;
+}
+
+uint32_t bce_pool_slots(const bce_ctx* c) { return c ? c->pool_slots : 0; }
+
+int bce_lwe_write(bce_ctx* c, const uint32_t* slots, uint32_t count, const uint64_t* cts) {
+    if (!c || !slots || !cts) return BCE_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t W = c->n + 1;
+    std::vector<u32> row(W);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (u32 i = 0; i < count; ++i) {
+        if (slots[i] >= c->pool_slots) return c->fail(BCE_ERR_POOL, "slot %u outside the pool", slots[i]);
+        for (size_t k = 0; k < W; ++k) {
+            if (cts[i * W + k] >= c->q) return c->fail(BCE_ERR_ARG, "ciphertext word not reduced mod q");
+            row[k] = (u32)cts[i * W + k];
+        }
+        HIP_TRY(c, hipMemcpy(c->d_pool + (size_t)slots[i] * c->P.pool_stride, row.data(), W * 4, hipMemcpyHostToDevice));
+    }
+    return BCE_OK;
+}
+
+int bce_lwe_read(bce_ctx* c, const uint32_t* slots, uint32_t count, uint64_t* cts) {
+    if (!c || !slots || !cts) return BCE_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t W = c->n + 1;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // one bulk copy when the request is dense enough, else per slot
+    u32 lo = ~0u, hi = 0;
+    for (u32 i = 0; i < count; ++i) {
+        if (slots[i] >= c->pool_slots) return c->fail(BCE_ERR_POOL, "slot %u outside the pool", slots[i]);
+        lo = std::min(lo, slots[i]);
+        hi = std::max(hi, slots[i]);
+    }
+    if (count == 0) return BCE_OK;
+    std::vector<u32> buf;
+    if ((u64)(hi - lo + 1) <= 4ull * count + 64) {
+        buf.resize((size_t)(hi - lo + 1) * W);
+        HIP_TRY(c, hipMemcpy(buf.data(), c->d_pool + (size_t)lo * W, buf.size() * 4, hipMemcpyDeviceToHost));
+        for (u32 i = 0; i < count; ++i)
+            for (size_t k = 0; k < W; ++k) cts[i * W + k] = buf[(size_t)(slots[i] - lo) * W + k];
+    } else {
+        buf.resize(W);
+        for (u32 i = 0; i < count; ++i) {
+            HIP_TRY(c, hipMemcpy(buf.data(), c->d_pool + (size_t)slots[i] * W, W * 4, hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < W; ++k) cts[i * W + k] = buf[k];
+        }
+    }
+    return BCE_OK;
+}
+
+int bce_encrypt_bits(bce_ctx* c, const uint8_t* bits, const uint32_t* slots, uint32_t count, uint64_t enc_index_base,
+                     int mode) {
+    if (!c || !bits || !slots) return BCE_ERR_ARG;
+    if (!c->have_keys) return c->fail(BCE_ERR_NO_KEYS, "no keys");
+    const u32 n = c->n;
+    const u64 q = c->q;
+    const size_t W = n + 1;
+    const GaussSampler gauss(3.19);
+    std::vector<u64> cts((size_t)count * W);
+    for (u32 i = 0; i < count; ++i) {
+        ChaChaStream st(c->seed, kDomENC, enc_index_base + i);
+        u64* ct = &cts[(size_t)i * W];
+        u128 acc = 0;
+        for (u32 k = 0; k < n; ++k) {
+            ct[k] = draw_uniform(st, q);
+            acc += (u128)ct[k] * lift_signed(c->s[k], q);
+        }
+        u64 e = lift_signed(gauss.draw(st), q);
+        ct[n] = (u64)((acc + e + (u64)(bits[i] % 4) * (q / 4)) % q);
+    }
+    int rc = bce_lwe_write(c, slots, count, cts.data());
+    if (rc) return rc;
+    if (mode == BCE_BOOTSTRAPPED) {
+        std::vector<bce_gate_desc> d(count);
+        for (u32 i = 0; i < count; ++i) d[i] = bce_gate_desc{BCE_OP_REFRESH, slots[i], slots[i], slots[i], 0, 0};
+        return bce_eval_gates(c, count, d.data());
+    }
+    return BCE_OK;
+}
+
+int bce_decrypt_bits(bce_ctx* c, const uint32_t* slots, uint32_t count, uint8_t* bits) {
+    if (!c || !slots || !bits) return BCE_ERR_ARG;
+    if (!c->have_keys) return c->fail(BCE_ERR_NO_KEYS, "no keys");
+    const u32 n = c->n;
+    const u64 q = c->q;
+    const size_t W = n + 1;
+    std::vector<u64> cts((size_t)count * W);
+    int rc = bce_lwe_read(c, slots, count, cts.data());
+    if (rc) return rc;
+    for (u32 i = 0; i < count; ++i) {
+        const u64* ct = &cts[(size_t)i * W];
+        u128 inner = 0;
+        for (u32 k = 0; k < n; ++k) inner += (u128)ct[k] * lift_signed(c->s[k], q);
+        u64 r = (ct[n] + q - (u64)(inner % q)) % q;
+        r = (r + q / 8) % q;
+        bits[i] = (uint8_t)((4 * r) / q);
+    }
+    return BCE_OK;
+}
+
+int bce_eval_gates(bce_ctx* c, uint32_t n_desc, const bce_gate_desc* descs) {
+    if (!c) return BCE_ERR_ARG;
+    return eval_impl(c, n_desc, descs, 1, 0, nullptr, nullptr, nullptr);
+}
+
+int bce_eval_gates_strided(bce_ctx* c, uint32_t n_desc, const bce_gate_desc* descs, uint32_t instances,
+                           uint32_t slot_stride) {
+    if (!c) return BCE_ERR_ARG;
+    return eval_impl(c, n_desc, descs, instances, slot_stride, nullptr, nullptr, nullptr);
+}
+
+int bce_synchronize(bce_ctx* c) {
+    if (!c) return BCE_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BCE_OK;
+}
+
+int bce_timing_reset(bce_ctx* c) {
+    if (!c) return BCE_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drain_timing(c);
+    c->timing = bce_timing{};
+    return BCE_OK;
+}
+
+int bce_timing_get(bce_ctx* c, bce_timing* out) {
+    if (!c || !out) return BCE_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drain_timing(c);
+    *out = c->timing;
+    return BCE_OK;
+}
+
+uint64_t bce_bytes_per_bootstrap(const bce_ctx* c) {
+    if (!c) return 0;
+    // w_bsk*[n*2*(2dG)*2*N] + w_ks*[N*dKS*(n+1)] + w_ct*[3(n+1)] at this build's widths
+    const u64 bsk = 4ull * c->n * 2 * (2 * c->dG) * 2 * c->N;
+    const u64 ks = (c->P.ksk_u16 ? 2ull : 4ull) * c->N * c->dKS * (c->n + 1);
+    const u64 ct = 4ull * 3 * (c->n + 1);
+    return bsk + ks + ct;
+}
+
+int bce_debug_eval_stages(bce_ctx* c, uint32_t n_desc, const bce_gate_desc* descs, uint64_t* acc, uint64_t* lweN,
+                          uint64_t* ks) {
+    if (!c) return BCE_ERR_ARG;
+    for (u32 i = 0; i < n_desc; ++i)
+        if (!(descs[i].op <= BCE_XNOR_FAST || descs[i].op == BCE_OP_REFRESH)) return c->fail(BCE_ERR_ARG, "staged outputs need bootstrapped ops only");
+    return eval_impl(c, n_desc, descs, 1, 0, acc, lweN, ks);
+}
+
+int bce_debug_ntt(bce_ctx* c, uint64_t* polys, uint32_t count, int inverse) {
+    if (!c || !polys) return BCE_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t words = (size_t)count * c->N;
+    std::vector<u32> tmp(words);
+    for (size_t i = 0; i < words; ++i) {
+        if (polys[i] >= c->Q) return c->fail(BCE_ERR_ARG, "poly word not reduced mod Q");
+        tmp[i] = (u32)polys[i];
+    }
+    u32* d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, words * 4));
+    HIP_TRY(c, hipMemcpy(d, tmp.data(), words * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, launch_ntt_batch(c->P, d, count, inverse, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(tmp.data(), d, words * 4, hipMemcpyDeviceToHost));
+    hipFree(d);
+    for (size_t i = 0; i < words; ++i) polys[i] = tmp[i];
+    return BCE_OK;
+}
+
+}  // extern "C"

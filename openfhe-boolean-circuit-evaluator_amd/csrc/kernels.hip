@@ -1,0 +1,557 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels of the gate-bootstrapping engine.
+//
+// Hot path replaced: OpenFHE's BinFHEContext::EvalBinGate as called by the reference at
+// src/gate.cpp:133,146,172,200-202 (one call per gate inside an OpenMP task,
+// src/circuit.cpp:698-710).  Here one workgroup runs one gate bootstrap:
+//
+//   k_blind_rotate_ginx   LWE prep (ct1+ct2, folded NOTs) -> test vector -> n x AddToAcc
+//                         (2 INTT, signed digit decomposition, 2*dG NTT, RGSW MAC with the
+//                         bootstrapping key streamed from HBM/L2, monomial multiply) -> INTT
+//   k_tail                transpose + sample extract + ModSwitch(Q->qKS) + LWE KeySwitch
+//                         (row gather) + ModSwitch(qKS->q)
+//
+// All arithmetic is 32-bit unsigned modular integer (Q < 2^28): Shoup/Harvey lazy
+// butterflies with values in [0,4Q) (forward) / [0,2Q) (inverse), 64-bit MAC sums reduced
+// by one Barrett step.  No MFMA: nothing here is a dense contraction.
+//
+// NTT organisation (64-wide wavefronts): ONE WAVE PER POLYNOMIAL, E = N/64 coefficients per
+// lane held in registers; log2(E) radix-2 stages run in registers per pass, with 2 (or 3)
+// LDS re-shuffles per transform instead of one barrier per stage.  A polynomial is stored
+// in LDS with 4 pad words per 64 so that all three access patterns are bank-conflict free.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace bce {
+
+// ---------------------------------------------------------------------------------------
+// modular arithmetic
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 csub(u32 x, u32 m) { return min(x, x - m); }  // x in [0,2m) -> [0,m)
+
+// y * w mod Q, lazily: result in [0, 2Q) for any 32-bit y.  w = (value, floor(value*2^32/Q))
+__device__ __forceinline__ u32 mul_shoup_lazy(u32 y, uint2 w, u32 Q) {
+    u32 qh = __umulhi(w.y, y);
+    return w.x * y - qh * Q;
+}
+
+// x < 2^(2*bitlen(Q)+3) -> x mod Q in [0, Q)
+__device__ __forceinline__ u32 barrett_reduce(u64 x, u32 Q, u32 shift, u32 mu) {
+    u32 x1 = (u32)(x >> shift);
+    u32 qh = __umulhi(x1, mu);
+    u32 r = (u32)x - qh * Q;  // < 3Q
+    r = csub(r, 2 * Q);
+    return csub(r, Q);
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS polynomial layout and register passes
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 phys(u32 j) { return j + ((j >> 6) << 2); }
+
+template <int LOGN>
+struct Cfg {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int LE = LOGN - 6;          // log2 coefficients per lane
+    static constexpr int E = 1 << LE;            // coefficients per lane
+    static constexpr int NP = N + (N >> 6) * 4;  // padded words per polynomial
+    static constexpr int F2LO = (6 > LE) ? 6 - LE : 0;  // low register bit of forward pass 2
+    static_assert(LOGN >= 9 && LOGN <= 11, "supported ring sizes: 512, 1024, 2048");
+};
+
+__device__ __forceinline__ void wave_sync() {
+    // LDS operations of one wave execute in order; this only pins the compiler.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// register r of lane `lane` holds coefficient j = (lane_hi << (LO+LE)) | (r << LO) | lane_lo
+template <int LOGN, int LO>
+__device__ __forceinline__ u32 elem_j(u32 lane, int r) {
+    constexpr int LE = Cfg<LOGN>::LE;
+    u32 lane_lo = lane & ((1u << LO) - 1u);
+    u32 lane_hi = lane >> LO;
+    return (lane_hi << (LO + LE)) | ((u32)r << LO) | lane_lo;
+}
+
+template <int LOGN, int LO>
+__device__ __forceinline__ void load_pass(const u32* poly, u32 lane, u32 (&x)[Cfg<LOGN>::E]) {
+    constexpr int E = Cfg<LOGN>::E;
+    if constexpr (LO == 0) {
+        const uint4* p = reinterpret_cast<const uint4*>(poly + phys(lane * E));
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) {
+            uint4 v = p[k];
+            x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < E; ++r) x[r] = poly[phys(elem_j<LOGN, LO>(lane, r))];
+    }
+}
+
+template <int LOGN, int LO>
+__device__ __forceinline__ void store_pass(u32* poly, u32 lane, const u32 (&x)[Cfg<LOGN>::E]) {
+    constexpr int E = Cfg<LOGN>::E;
+    if constexpr (LO == 0) {
+        uint4* p = reinterpret_cast<uint4*>(poly + phys(lane * E));
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) p[k] = make_uint4(x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < E; ++r) poly[phys(elem_j<LOGN, LO>(lane, r))] = x[r];
+    }
+}
+
+// Cooley-Tukey stage on coefficient-index bit B (distance 2^B), twiddle tw[m + (j >> (B+1))]
+template <int LOGN, int LO, int B>
+__device__ __forceinline__ void fwd_stage(u32 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q) {
+    constexpr int LE = Cfg<LOGN>::LE, E = Cfg<LOGN>::E;
+    constexpr int rb = B - LO;
+    constexpr u32 m = 1u << (LOGN - 1 - B);
+    const u32 hi = (lane >> LO) << (LO + LE - B - 1);
+    const u32 Q2 = 2 * Q;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        if (r & (1 << rb)) continue;
+        uint2 w = tw[m + (hi | (u32)(r >> (rb + 1)))];
+        u32 X = csub(x[r], Q2);
+        u32 T = mul_shoup_lazy(x[r | (1 << rb)], w, Q);
+        x[r] = X + T;
+        x[r | (1 << rb)] = X + Q2 - T;
+    }
+}
+
+// Gentleman-Sande stage on bit B; values stay in [0, 2Q)
+template <int LOGN, int LO, int B>
+__device__ __forceinline__ void inv_stage(u32 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q) {
+    constexpr int LE = Cfg<LOGN>::LE, E = Cfg<LOGN>::E;
+    constexpr int rb = B - LO;
+    constexpr u32 m = 1u << (LOGN - 1 - B);
+    const u32 hi = (lane >> LO) << (LO + LE - B - 1);
+    const u32 Q2 = 2 * Q;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        if (r & (1 << rb)) continue;
+        uint2 w = tw[m + (hi | (u32)(r >> (rb + 1)))];
+        u32 X = x[r], Y = x[r | (1 << rb)];
+        x[r] = csub(X + Y, Q2);
+        x[r | (1 << rb)] = mul_shoup_lazy(X + Q2 - Y, w, Q);
+    }
+}
+
+template <int LOGN, int LO, int BHI, int BLO>
+__device__ __forceinline__ void fwd_stages(u32 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q) {
+    if constexpr (BHI >= BLO) {
+        fwd_stage<LOGN, LO, BHI>(x, lane, tw, Q);
+        fwd_stages<LOGN, LO, BHI - 1, BLO>(x, lane, tw, Q);
+    }
+}
+template <int LOGN, int LO, int BLO, int BHI>
+__device__ __forceinline__ void inv_stages(u32 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q) {
+    if constexpr (BLO <= BHI) {
+        inv_stage<LOGN, LO, BLO>(x, lane, tw, Q);
+        inv_stages<LOGN, LO, BLO + 1, BHI>(x, lane, tw, Q);
+    }
+}
+
+// Forward negacyclic NTT of one polynomial by one wave, in place in LDS.
+// Input: natural order, values < 4Q.  Output: bit-reversed order, values in [0, Q).
+template <int LOGN>
+__device__ __forceinline__ void ntt_forward_wave(u32* poly, const uint2* twf, u32 lane, u32 Q) {
+    using C = Cfg<LOGN>;
+    u32 x[C::E];
+    load_pass<LOGN, 6>(poly, lane, x);
+    fwd_stages<LOGN, 6, LOGN - 1, 6>(x, lane, twf, Q);
+    store_pass<LOGN, 6>(poly, lane, x);
+    wave_sync();
+    load_pass<LOGN, C::F2LO>(poly, lane, x);
+    fwd_stages<LOGN, C::F2LO, 5, C::F2LO>(x, lane, twf, Q);
+    if constexpr (C::F2LO > 0) {
+        store_pass<LOGN, C::F2LO>(poly, lane, x);
+        wave_sync();
+        load_pass<LOGN, 0>(poly, lane, x);
+        fwd_stages<LOGN, 0, C::F2LO - 1, 0>(x, lane, twf, Q);
+    }
+#pragma unroll
+    for (int r = 0; r < C::E; ++r) x[r] = csub(csub(x[r], 2 * Q), Q);
+    store_pass<LOGN, 0>(poly, lane, x);
+    wave_sync();
+}
+
+// Inverse NTT by one wave: reads `src` (bit-reversed order, values < 2Q), uses `tmp` for the
+// re-shuffles (may alias src), leaves coefficient j = (r << 6) | lane in x[r], in [0, Q).
+template <int LOGN>
+__device__ __forceinline__ void ntt_inverse_wave(const u32* src, u32* tmp, const uint2* twi, u32 lane, u32 Q,
+                                                 uint2 ninv, u32 (&x)[Cfg<LOGN>::E]) {
+    using C = Cfg<LOGN>;
+    constexpr int LE = C::LE;
+    load_pass<LOGN, 0>(src, lane, x);
+    inv_stages<LOGN, 0, 0, LE - 1>(x, lane, twi, Q);
+    store_pass<LOGN, 0>(tmp, lane, x);
+    wave_sync();
+    load_pass<LOGN, LE>(tmp, lane, x);
+    inv_stages<LOGN, LE, LE, 2 * LE - 1>(x, lane, twi, Q);
+    store_pass<LOGN, LE>(tmp, lane, x);
+    wave_sync();
+    load_pass<LOGN, 6>(tmp, lane, x);
+    inv_stages<LOGN, 6, 2 * LE, LOGN - 1>(x, lane, twi, Q);
+#pragma unroll
+    for (int r = 0; r < C::E; ++r) x[r] = csub(mul_shoup_lazy(x[r], ninv, Q), Q);
+}
+
+// psi^e for e in [0, 2N) from the forward table (tw_f[brv(i)] = psi^i, psi^(i+N) = -psi^i)
+template <int LOGN>
+__device__ __forceinline__ u32 psi_pow(const uint2* twf, u32 e, u32 Q) {
+    constexpr u32 N = 1u << LOGN;
+    u32 v = twf[__brev(e & (N - 1)) >> (32 - LOGN)].x;
+    return (e & N) ? Q - v : v;
+}
+
+// gate constant q1 of BootstrapGateCore (OR 5q/8, AND 7q/8, NOR q/8, NAND 3q/8)
+__device__ __forceinline__ u32 gate_const(u32 op, u32 q) {
+    u32 e = q >> 3;
+    switch (op) {
+        case BCE_OR: case BCE_XOR_FAST: return 5 * e;
+        case BCE_NOR: case BCE_XNOR_FAST: return e;
+        case BCE_NAND: return 3 * e;
+        default: return 7 * e;  // AND, REFRESH
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// blind rotation (GINX / CGGI): one workgroup = one gate bootstrap, one wave per RGSW row
+// ---------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(512) void k_blind_rotate_ginx(DevParams P, const bce_gate_desc* __restrict__ descs,
+                                                           u32 n_desc, u32 slot_stride, u32* __restrict__ acc_out) {
+    using C = Cfg<LOGN>;
+    constexpr int N = C::N, NP = C::NP, E = C::E;
+    extern __shared__ __align__(16) u32 smem[];
+    const u32 R = 2 * P.dG;
+    uint2* twf = reinterpret_cast<uint2*>(smem);
+    uint2* twi = twf + N;
+    u32* acc = reinterpret_cast<u32*>(twi + N);  // [2][NP]  EVALUATION domain, [0,Q)
+    u32* dct = acc + 2 * NP;                     // [R][NP]
+    u32* av = dct + R * NP;                      // ctprep: a[0..n), b
+
+    const u32 tid = threadIdx.x, T = blockDim.x;
+    const u32 lane = tid & 63, wave = tid >> 6;
+    const u32 Q = P.Q, q = P.q, qm = q - 1, n = P.n;
+
+    const bce_gate_desc g = descs[blockIdx.x % n_desc];
+    const u32 soff = (blockIdx.x / n_desc) * slot_stride;
+
+    for (u32 i = tid; i < (u32)N; i += T) {
+        twf[i] = P.tw_f[i];
+        twi[i] = P.tw_i[i];
+    }
+    {   // EvalBinGate LWE prep with folded EvalNOT: (-a, q/4 - b)
+        const u32* in0 = P.pool + (size_t)(g.in0 + soff) * P.pool_stride;
+        const u32* in1 = P.pool + (size_t)(g.in1 + soff) * P.pool_stride;
+        const bool two = g.op <= BCE_XNOR_FAST;
+        for (u32 i = tid; i <= n; i += T) {
+            u32 v0 = in0[i];
+            if (g.neg0) v0 = ((i == n ? (q >> 2) : 0u) - v0) & qm;
+            u32 v = v0;
+            if (two) {
+                u32 v1 = in1[i];
+                if (g.neg1) v1 = ((i == n ? (q >> 2) : 0u) - v1) & qm;
+                v = (g.op == BCE_XOR_FAST || g.op == BCE_XNOR_FAST) ? (2u * (v0 - v1)) & qm : (v0 + v1) & qm;
+            } else if (i == n) {
+                v = (v0 + (q >> 2)) & qm;  // Bootstrap(): ct + q/4
+            }
+            av[i] = v;
+        }
+    }
+    __syncthreads();
+    {   // BootstrapGateCore: acc = (0, m(X)), m sparse with +-(Q/8+1)
+        const u32 b = av[n];
+        const u32 q1 = gate_const(g.op, q), q2 = (q1 + (q >> 1)) & qm;
+        const u32 pos = P.Q8p1, neg = Q - P.Q8p1;
+        for (u32 j = tid; j < (u32)N; j += T) {
+            u32 v = 0;
+            if (j % P.factor == 0) {
+                u32 t = (b - j / P.factor) & qm;
+                bool in = (q1 < q2) ? (t >= q1 && t < q2) : !(t >= q2 && t < q1);
+                v = in ? neg : pos;
+            }
+            acc[phys(j)] = 0;
+            acc[NP + phys(j)] = v;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) ntt_forward_wave<LOGN>(acc + NP, twf, lane, Q);
+    __syncthreads();
+
+    const uint2 ninv = make_uint2(P.Ninv, P.Ninv_s);
+    const int gsh = 32 - (int)P.gBits;
+    const u32 Qh = Q >> 1;
+    const size_t rgsw = (size_t)R * 2 * N;  // words per RGSW ciphertext
+
+    for (u32 i = 0; i < n; ++i) {
+        const u32 ap = ((q - av[i]) & qm) * P.factor;  // exponent of the monomial, in [0, 2N)
+        if (ap == 0) continue;                          // X^0 - 1 = 0: AddToAcc adds nothing
+
+        // (1) two waves: INTT of acc[c], SignedDigitDecompose -> dct[2l + c] (coefficient form)
+        if (wave < 2) {
+            u32 x[E];
+            ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, twi, lane, Q, ninv, x);
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                int d = (x[r] < Qh) ? (int)x[r] : (int)x[r] - (int)Q;
+                const u32 pj = phys(((u32)r << 6) | lane);
+                for (u32 l = 0; l < P.dG; ++l) {
+                    int rem = (int)((u32)d << gsh) >> gsh;  // signed digit in [-B/2, B/2)
+                    d = (d - rem) >> P.gBits;
+                    dct[(2 * l + wave) * NP + pj] = rem < 0 ? (u32)(rem + (int)Q) : (u32)rem;
+                }
+            }
+        }
+        __syncthreads();
+        // (2) one wave per decomposed polynomial: forward NTT in place
+        if (wave < R) ntt_forward_wave<LOGN>(dct + wave * NP, twf, lane, Q);
+        __syncthreads();
+        // (3) RGSW multiply-accumulate against ek+_i, ek-_i and the two monomials
+        const u32* bk = P.bsk + (size_t)i * 2 * rgsw;
+        for (u32 item = tid; item < 2u * (N / 4); item += T) {
+            const u32 c = item / (N / 4), p0 = (item % (N / 4)) * 4;
+            const u32 pp = phys(p0);
+            u64 sp[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0};
+            for (u32 l = 0; l < R; ++l) {
+                const uint4 d = *reinterpret_cast<const uint4*>(dct + l * NP + pp);
+                const uint4 kp = *reinterpret_cast<const uint4*>(bk + ((size_t)l * 2 + c) * N + p0);
+                const uint4 kn = *reinterpret_cast<const uint4*>(bk + rgsw + ((size_t)l * 2 + c) * N + p0);
+                sp[0] += (u64)d.x * kp.x; sp[1] += (u64)d.y * kp.y; sp[2] += (u64)d.z * kp.z; sp[3] += (u64)d.w * kp.w;
+                sn[0] += (u64)d.x * kn.x; sn[1] += (u64)d.y * kn.y; sn[2] += (u64)d.z * kn.z; sn[3] += (u64)d.w * kn.w;
+            }
+            uint4 a4 = *reinterpret_cast<const uint4*>(acc + c * NP + pp);
+            u32 a[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // evaluation point of position p is psi^(2*brv(p)+1); mono = psi^((2k+1)*a') - 1
+                const u32 k = __brev(p0 + e) >> (32 - LOGN);
+                const u32 ex = ((2 * k + 1) * ap) & (2 * N - 1);
+                const u32 mp = psi_pow<LOGN>(twf, ex, Q) - 1;
+                const u32 mn = psi_pow<LOGN>(twf, (2 * N - ex) & (2 * N - 1), Q) - 1;
+                const u32 rp = barrett_reduce(sp[e], Q, P.red_shift, P.red_mu);
+                const u32 rn = barrett_reduce(sn[e], Q, P.red_shift, P.red_mu);
+                a[e] = barrett_reduce((u64)rp * mp + (u64)rn * mn + a[e], Q, P.red_shift, P.red_mu);
+            }
+            *reinterpret_cast<uint4*>(acc + c * NP + pp) = make_uint4(a[0], a[1], a[2], a[3]);
+        }
+        __syncthreads();
+    }
+
+    // accumulator back to COEFFICIENT form for the extraction kernel
+    if (wave < 2) {
+        u32 x[E];
+        ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, twi, lane, Q, ninv, x);
+        u32* out = acc_out + ((size_t)blockIdx.x * 2 + wave) * N;
+#pragma unroll
+        for (int r = 0; r < E; ++r) out[((u32)r << 6) | lane] = x[r];
+    }
+}
+
+size_t blind_rotate_lds_bytes(const DevParams& P) {
+    const size_t N = P.N, NP = N + (N >> 6) * 4, R = 2 * P.dG;
+    return (2 * N * 2 + (2 + R) * NP + ((P.n + 1 + 3) & ~3u)) * sizeof(u32);
+}
+
+hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
+                               u32* acc_out, hipStream_t s) {
+    const u32 R = 2 * P.dG;
+    const dim3 grid(n_desc * instances), block(64 * (R < 2 ? 2 : R));
+    const size_t lds = blind_rotate_lds_bytes(P);
+    void (*kern)(DevParams, const bce_gate_desc*, u32, u32, u32*) = nullptr;
+    switch (P.logN) {
+        case 9: kern = k_blind_rotate_ginx<9>; break;
+        case 10: kern = k_blind_rotate_ginx<10>; break;
+        case 11: kern = k_blind_rotate_ginx<11>; break;
+        default: return hipErrorInvalidValue;
+    }
+    if (block.x > 512) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, grid, block, lds, s, P, d, n_desc, slot_stride, acc_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// tail: extract + ModSwitch + KeySwitch + ModSwitch (one workgroup per bootstrap)
+// ---------------------------------------------------------------------------------------
+// LWEEncryptionScheme::RoundqQ restated with the same three IEEE double operations
+// (compiled with -ffp-contract=off): floor(0.5 + double(v) * double(q) / double(Q)) mod q
+__device__ __forceinline__ u32 round_qQ(u32 v, u32 q, u32 Qfrom) {
+    double t = (double)v * (double)q;
+    t = t / (double)Qfrom;
+    u64 r = (u64)floor(0.5 + t);
+    return (u32)(r >= q ? r - q : r);
+}
+
+template <typename KT, typename ACC>
+__global__ __launch_bounds__(256) void k_tail(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
+                                              u32 slot_stride, const u32* __restrict__ acc_in,
+                                              u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
+    extern __shared__ __align__(16) u32 smem[];
+    const u32 N = P.N, n = P.n, Q = P.Q, qKS = P.qKS, B = P.baseKS, D = P.dKS;
+    u32* rowidx = smem;  // [N*D] row number (i*B + digit)*D + j
+    __shared__ u32 s_b;
+    const u32 tid = threadIdx.x, T = blockDim.x;
+    const u32* a0 = acc_in + (size_t)blockIdx.x * 2 * N;
+    const u32* a1 = a0 + N;
+
+    // Transpose (X -> X^-1) of acc[0]: a'_0 = a_0, a'_{N-i} = -a_i ; then ModSwitch(Q -> qKS)
+    for (u32 i = tid; i < N; i += T) {
+        u32 src = (i == 0) ? a0[0] : a0[N - i];
+        u32 v = (i == 0) ? src : (src ? Q - src : 0u);
+        u32 at = round_qQ(v, qKS, Q);
+        if (dbg_lweN) dbg_lweN[(size_t)blockIdx.x * (N + 1) + i] = at;
+        for (u32 j = 0; j < D; ++j) {
+            rowidx[i * D + j] = (i * B + at % B) * D + j;
+            at /= B;
+        }
+    }
+    if (tid == 0) {
+        u32 b = a1[0] + P.Q8p1;
+        b = b >= Q ? b - Q : b;
+        b = round_qQ(b, qKS, Q);
+        s_b = b;
+        if (dbg_lweN) dbg_lweN[(size_t)blockIdx.x * (N + 1) + N] = b;
+    }
+    __syncthreads();
+
+    // KeySwitch: a' = -sum_rows A[row], b' = b - sum_rows B[row]   (mod qKS)
+    const KT* ksk = reinterpret_cast<const KT*>(P.ksk);
+    const u32 rows = N * D;
+    const bce_gate_desc g = descs[blockIdx.x % n_desc];
+    u32* out = P.pool + (size_t)(g.out + (blockIdx.x / n_desc) * slot_stride) * P.pool_stride;
+    for (u32 k = tid; k <= n; k += T) {
+        ACC s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        u32 r = 0;
+        for (; r + 4 <= rows; r += 4) {
+            s0 += ksk[(size_t)rowidx[r] * P.ksk_stride + k];
+            s1 += ksk[(size_t)rowidx[r + 1] * P.ksk_stride + k];
+            s2 += ksk[(size_t)rowidx[r + 2] * P.ksk_stride + k];
+            s3 += ksk[(size_t)rowidx[r + 3] * P.ksk_stride + k];
+        }
+        for (; r < rows; ++r) s0 += ksk[(size_t)rowidx[r] * P.ksk_stride + k];
+        u64 sum = (u64)s0 + (u64)s1 + (u64)s2 + (u64)s3;
+        u32 sm = (u32)(sum % qKS);
+        u32 base = (k == n) ? s_b : 0u;
+        u32 v = base >= sm ? base - sm : base + qKS - sm;
+        if (dbg_ks) dbg_ks[(size_t)blockIdx.x * (n + 1) + k] = v;
+        out[k] = round_qQ(v, P.q, qKS);  // ModSwitch(qKS -> q)
+    }
+}
+
+hipError_t launch_tail(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
+                       const u32* acc_in, u32* dbg_lweN, u32* dbg_ks, hipStream_t s) {
+    const dim3 grid(n_desc * instances), block(256);
+    const size_t lds = (size_t)P.N * P.dKS * sizeof(u32);
+    if (P.ksk_u16) {
+        hipLaunchKernelGGL((k_tail<uint16_t, u32>), grid, block, lds, s, P, d, n_desc, slot_stride, acc_in, dbg_lweN, dbg_ks);
+    } else {
+        hipLaunchKernelGGL((k_tail<u32, u64>), grid, block, lds, s, P, d, n_desc, slot_stride, acc_in, dbg_lweN, dbg_ks);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// EvalNOT / COPY
+// ---------------------------------------------------------------------------------------
+__global__ void k_lwe_unary(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc, u32 slot_stride) {
+    const bce_gate_desc g = descs[blockIdx.x % n_desc];
+    const u32 soff = (blockIdx.x / n_desc) * slot_stride;
+    const u32* in = P.pool + (size_t)(g.in0 + soff) * P.pool_stride;
+    u32* out = P.pool + (size_t)(g.out + soff) * P.pool_stride;
+    const u32 qm = P.q - 1;
+    const bool neg = (g.op == BCE_OP_NOT) != (g.neg0 != 0);
+    for (u32 i = threadIdx.x; i <= P.n; i += blockDim.x) {
+        u32 v = in[i];
+        if (neg) v = ((i == P.n ? (P.q >> 2) : 0u) - v) & qm;
+        out[i] = v;
+    }
+}
+
+hipError_t launch_lwe_unary(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
+                            hipStream_t s) {
+    hipLaunchKernelGGL(k_lwe_unary, dim3(n_desc * instances), dim3(256), 0, s, P, d, n_desc, slot_stride);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// batched NTT over global memory (key import / key generation / debug), one wave per poly
+// ---------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_ntt_batch(DevParams P, u32* __restrict__ polys, u32 count, int inverse) {
+    using C = Cfg<LOGN>;
+    constexpr int N = C::N, NP = C::NP, E = C::E;
+    extern __shared__ __align__(16) u32 smem[];
+    uint2* tw = reinterpret_cast<uint2*>(smem);
+    u32* buf = reinterpret_cast<u32*>(tw + N);
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    const uint2* src = inverse ? P.tw_i : P.tw_f;
+    for (u32 i = tid; i < (u32)N; i += blockDim.x) tw[i] = src[i];
+    __syncthreads();
+    u32* mine = buf + wave * NP;
+    for (u32 p = blockIdx.x * W + wave; p < count; p += gridDim.x * W) {
+        u32* gp = polys + (size_t)p * N;
+        for (int r = 0; r < E; ++r) {
+            u32 j = ((u32)r << 6) | lane;
+            mine[phys(j)] = gp[j];
+        }
+        wave_sync();
+        if (!inverse) {
+            ntt_forward_wave<LOGN>(mine, tw, lane, P.Q);
+            for (int r = 0; r < E; ++r) {
+                u32 j = ((u32)r << 6) | lane;
+                gp[j] = mine[phys(j)];
+            }
+        } else {
+            u32 x[E];
+            ntt_inverse_wave<LOGN>(mine, mine, tw, lane, P.Q, make_uint2(P.Ninv, P.Ninv_s), x);
+#pragma unroll
+            for (int r = 0; r < E; ++r) gp[((u32)r << 6) | lane] = x[r];
+        }
+        wave_sync();
+    }
+}
+
+hipError_t launch_ntt_batch(const DevParams& P, u32* polys, u32 count, int inverse, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    const size_t N = P.N, NP = N + (N >> 6) * 4;
+    const u32 W = 4;
+    const size_t lds = (2 * N + W * NP) * sizeof(u32);
+    u32 blocks = (count + W - 1) / W;
+    if (blocks > 4096) blocks = 4096;
+    void (*kern)(DevParams, u32*, u32, int) = nullptr;
+    switch (P.logN) {
+        case 9: kern = k_ntt_batch<9>; break;
+        case 10: kern = k_ntt_batch<10>; break;
+        case 11: kern = k_ntt_batch<11>; break;
+        default: return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), lds, s, P, polys, count, inverse);
+    return hipGetLastError();
+}
+
+__global__ void k_pointwise_mac(DevParams P, u32* __restrict__ b, const u32* __restrict__ a,
+                                const u32* __restrict__ z, u32 count, u32 b_step) {
+    const size_t total = (size_t)count * P.N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const u32 k = (u32)(i & (P.N - 1));
+        const size_t bi = (i >> P.logN) * b_step * P.N + k;
+        b[bi] = barrett_reduce((u64)a[i] * z[k] + b[bi], P.Q, P.red_shift, P.red_mu);
+    }
+}
+
+hipError_t launch_pointwise_mac(const DevParams& P, u32* b, const u32* a, const u32* z, u32 count, u32 b_step,
+                                hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pointwise_mac, dim3(2048), dim3(256), 0, s, P, b, a, z, count, b_step);
+    return hipGetLastError();
+}
+
+}  // namespace bce

@@ -1,0 +1,63 @@
+// kernels.hpp -- launch interface of the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "../../include/bce_gpu.h"
+
+namespace bce {
+
+using u32 = uint32_t;
+using u64 = uint64_t;
+
+// Everything a kernel needs, passed by value (lives in SGPRs / kernarg).
+struct DevParams {
+    u32 n, N, logN;
+    u32 q;            // LWE modulus, power of two
+    u32 Q;            // ring modulus, prime < 2^28, Q = 1 mod 2N
+    u32 qKS;          // key-switch modulus
+    u32 baseKS, dKS;
+    u32 ksk_stride;   // elements per KSK row (>= n+1, padded)
+    u32 ksk_u16;      // 1: rows are uint16_t, 0: uint32_t
+    u32 gBits, dG;    // gadget: base 2^gBits, dG digits; R = 2*dG RGSW rows
+    u32 baseR, dR;    // AP only
+    u32 factor;       // 2N / q
+    u32 Q8p1;         // Q/8 + 1
+    u32 red_shift;    // Barrett for x < 2^(2*bitlen(Q)+3): x1 = x >> red_shift
+    u32 red_mu;       // floor(2^(32+red_shift) / Q)
+    u32 Ninv, Ninv_s; // N^-1 mod Q and its Shoup companion
+    const uint2* tw_f;  // [N] (psi^brv(i), shoup), index m+i as in the CT forward NTT
+    const uint2* tw_i;  // [N] inverse powers, GS order
+    const u32* bsk;     // EVALUATION domain, GINX [n][2][R][2][N]; AP [n][baseR][dR][R][2][N]
+    const void* ksk;    // [N][baseKS][dKS][ksk_stride]
+    u32* pool;          // [slots][pool_stride]
+    u32 pool_stride;
+};
+
+// LDS bytes the blind-rotation kernel needs for these parameters
+size_t blind_rotate_lds_bytes(const DevParams& P);
+
+// acc_out: u32 [n_boot][2][N], COEFFICIENT domain, values in [0, Q)
+hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances,
+                               u32 slot_stride, u32* acc_out, hipStream_t s);
+
+// extract + ModSwitch(Q->qKS) + KeySwitch + ModSwitch(qKS->q) -> pool[out]
+// dbg_lweN: u32 [n_boot][N+1] or null; dbg_ks: u32 [n_boot][n+1] or null
+hipError_t launch_tail(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances, u32 slot_stride,
+                       const u32* acc_in, u32* dbg_lweN, u32* dbg_ks, hipStream_t s);
+
+// EvalNOT / COPY over pool slots
+hipError_t launch_lwe_unary(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances,
+                            u32 slot_stride, hipStream_t s);
+
+// in-place negacyclic NTT of `count` polys, u32 [count][N] in global memory
+hipError_t launch_ntt_batch(const DevParams& P, u32* polys, u32 count, int inverse, hipStream_t s);
+
+// b[p*b_step][k] += a[p][k] * z[k] mod Q for count polys (key generation)
+hipError_t launch_pointwise_mac(const DevParams& P, u32* b, const u32* a, const u32* z, u32 count, u32 b_step,
+                                hipStream_t s);
+
+// host-side decrypt helper kernels are not needed: decryption happens on the host (needs sk)
+
+}  // namespace bce

@@ -1,0 +1,189 @@
+"""GPU parity of the HIP engine against the CPU oracle, through the C ABI (include/bce_gpu.h).
+
+Bar: bit-exact (all integer arithmetic; the only floating point is RoundqQ, restated with
+the same IEEE double operations).  The oracle is a restatement of OpenFHE's algorithm, not
+OpenFHE itself: ciphertext-level parity against OpenFHE is unpinned (see oracle header).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x0FE5EED
+
+
+def _pair(bce, orc, ps_name, seed=SEED):
+    ps_b = getattr(bce, ps_name)
+    ps_o = getattr(orc, ps_name)
+    o = orc.Oracle(ps_o, orc.GINX)
+    o.keygen(seed)
+    c = bce.BinFHEContext(ps_b, bce.GINX)
+    c.import_keys(o.sk(), o.z(), o.bsk(), o.ksk())
+    return o, c
+
+
+@pytest.fixture(scope="module")
+def toy(bce, orc):
+    return _pair(bce, orc, "TOY")
+
+
+@pytest.fixture(scope="module")
+def std128(bce, orc):
+    return _pair(bce, orc, "STD128_OPT")
+
+
+def test_params_match(toy, std128):
+    for o, c in (toy, std128):
+        assert o.params == c.params
+
+
+@pytest.mark.parametrize("which", ["toy", "std128"])
+def test_ntt_matches_oracle(which, request):
+    o, c = request.getfixturevalue(which)
+    rng = np.random.default_rng(1)
+    polys = rng.integers(0, o.params["Q"], size=(5, o.N), dtype=np.uint64)
+    polys[0] = 0
+    polys[0, 1] = 1          # X
+    polys[1] = o.params["Q"] - 1
+    fwd = c.debug_ntt(polys, inverse=False)
+    for k in range(polys.shape[0]):
+        assert np.array_equal(fwd[k], o.ntt_forward(polys[k])), "forward NTT differs from oracle, poly %d" % k
+    back = c.debug_ntt(fwd, inverse=True)
+    assert np.array_equal(back, polys)
+
+
+def _gate_cases(o, base=0):
+    """all (gate, a, b) input combinations with fresh oracle encryptions"""
+    cases, idx = [], base
+    for gate in range(6):
+        for a in (0, 1):
+            for b in (0, 1):
+                cases.append((gate, a, b, o.encrypt(a, idx), o.encrypt(b, idx + 1)))
+                idx += 2
+    return cases
+
+
+def _truth(gate, a, b):
+    return [a | b, a & b, 1 - (a | b), 1 - (a & b), a ^ b, 1 - (a ^ b)][gate]
+
+
+def test_toy_all_gates_bit_exact_stages(toy, bce):
+    o, c = toy
+    cases = _gate_cases(o)
+    nb = len(cases)
+    c.pool_reserve(3 * nb)
+    slots = np.arange(2 * nb, dtype=np.uint32)
+    c.lwe_write(slots, np.concatenate([np.stack([ca, cb]) for (_, _, _, ca, cb) in cases]))
+    descs = [(g, 2 * i, 2 * i + 1, 2 * nb + i) for i, (g, _, _, _, _) in enumerate(cases)]
+    acc, lweN, ks = c.debug_eval_stages(descs)
+    out = c.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32))
+    bits = c.Decrypt(np.arange(2 * nb, 3 * nb, dtype=np.uint32))
+    for i, (g, a, b, ca, cb) in enumerate(cases):
+        prep = o.gate_prep(g, ca, cb)
+        r_acc = o.blind_rotate(g, prep)
+        assert np.array_equal(acc[i], r_acc), "accumulator differs, case %d" % i
+        r_lweN = o.extract_modswitch(r_acc)
+        assert np.array_equal(lweN[i], r_lweN), "extract/modswitch differs, case %d" % i
+        r_ks = o.keyswitch(r_lweN)
+        assert np.array_equal(ks[i], r_ks), "keyswitch differs, case %d" % i
+        r_out = o.modswitch_final(r_ks)
+        assert np.array_equal(out[i], r_out), "final ciphertext differs, case %d" % i
+        assert np.array_equal(out[i], o.eval_bingate(g, ca, cb))
+        assert bits[i] == _truth(g, a, b) == o.decrypt(out[i])
+
+
+def test_std128_gates_bit_exact(std128, bce):
+    o, c = std128
+    cases = [x for x in _gate_cases(o, base=1000) if x[0] in (bce.AND, bce.OR, bce.NAND)][:6]
+    nb = len(cases)
+    c.pool_reserve(3 * nb)
+    c.lwe_write(np.arange(2 * nb, dtype=np.uint32), np.concatenate([np.stack([ca, cb]) for (_, _, _, ca, cb) in cases]))
+    descs = [(g, 2 * i, 2 * i + 1, 2 * nb + i) for i, (g, _, _, _, _) in enumerate(cases)]
+    acc, lweN, ks = c.debug_eval_stages(descs)
+    out = c.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32))
+    for i, (g, a, b, ca, cb) in enumerate(cases):
+        r_acc = o.blind_rotate(g, o.gate_prep(g, ca, cb))
+        assert np.array_equal(acc[i], r_acc), "accumulator differs, case %d" % i
+        r_lweN = o.extract_modswitch(r_acc)
+        assert np.array_equal(lweN[i], r_lweN)
+        r_ks = o.keyswitch(r_lweN)
+        assert np.array_equal(ks[i], r_ks)
+        assert np.array_equal(out[i], o.modswitch_final(r_ks))
+        assert o.decrypt(out[i]) == _truth(g, a, b)
+
+
+def test_folded_not_refresh_and_unary(toy, bce):
+    """neg0/neg1 folding == explicit EvalNOT; REFRESH == Bootstrap(); NOT/COPY ops."""
+    o, c = toy
+    ca, cb = o.encrypt(1, 5000), o.encrypt(0, 5001)
+    c.pool_reserve(16)
+    c.lwe_write([0, 1], np.stack([ca, cb]))
+    c.EvalGates([(bce.AND, 0, 1, 2, 0, 1),      # a AND !b
+                 (bce.AND, 0, 1, 3, 1, 0),      # !a AND b
+                 (bce.OP_REFRESH, 0, 0, 4),
+                 (bce.OP_NOT, 1, 1, 5),
+                 (bce.OP_COPY, 0, 0, 6)])
+    out = c.lwe_read([2, 3, 4, 5, 6])
+    assert np.array_equal(out[0], o.eval_bingate(orc_and(bce), ca, o.eval_not(cb)))
+    assert np.array_equal(out[1], o.eval_bingate(orc_and(bce), o.eval_not(ca), cb))
+    assert np.array_equal(out[2], o.bootstrap(ca))
+    assert np.array_equal(out[3], o.eval_not(cb))
+    assert np.array_equal(out[4], ca)
+    # XOR the reference's way (src/gate.cpp:198-202): OR of the two ANDs
+    c.EvalGates([(bce.OR, 2, 3, 7)])
+    x = c.lwe_read([7])[0]
+    assert np.array_equal(x, o.eval_bingate(0, out[0], out[1]))
+    assert o.decrypt(x) == 1
+
+
+def orc_and(bce):
+    return bce.AND  # same numeric value in the oracle (BINGATE order)
+
+
+def test_keygen_matches_oracle_keygen(bce, orc):
+    """Independent host PRNG/sampler implementations + device NTT give identical keys."""
+    o = orc.Oracle(orc.TOY, orc.GINX)
+    o.keygen(1234567)
+    c = bce.BinFHEContext(bce.TOY, bce.GINX)
+    c.KeyGen(1234567)
+    s, z = c.export_sk()
+    assert np.array_equal(s, o.sk()) and np.array_equal(z, o.z())
+    assert np.array_equal(c.export_ksk(), o.ksk())
+    assert np.array_equal(c.export_bsk(), o.bsk())
+    # and the engine's own Encrypt uses the same stream as the oracle's
+    c.pool_reserve(4)
+    c.Encrypt([1, 0, 1], [0, 1, 2], enc_index_base=77)
+    got = c.lwe_read([0, 1, 2])
+    for k, bit in enumerate([1, 0, 1]):
+        assert np.array_equal(got[k], o.encrypt(bit, 77 + k))
+    assert list(c.Decrypt([0, 1, 2])) == [1, 0, 1]
+
+
+def test_strided_instances(toy, bce):
+    o, c = toy
+    K, stride = 3, 8
+    c.pool_reserve(K * stride)
+    ins = []
+    for k in range(K):
+        ca, cb = o.encrypt(k & 1, 9000 + 2 * k), o.encrypt(1, 9001 + 2 * k)
+        ins.append((ca, cb))
+        c.lwe_write([k * stride, k * stride + 1], np.stack([ca, cb]))
+    c.EvalGates([(bce.NAND, 0, 1, 2), (bce.OR, 0, 1, 3)], instances=K, slot_stride=stride)
+    for k in range(K):
+        out = c.lwe_read([k * stride + 2, k * stride + 3])
+        assert np.array_equal(out[0], o.eval_bingate(bce.NAND, *ins[k]))
+        assert np.array_equal(out[1], o.eval_bingate(bce.OR, *ins[k]))
+
+
+def test_errors_are_reported_not_thrown(bce):
+    c = bce.BinFHEContext(bce.TOY, bce.GINX)
+    with pytest.raises(bce.BceError) as e:
+        c.EvalGates([(bce.AND, 0, 1, 2)])
+    assert e.value.code == bce.ERR_NO_KEYS
+    c.KeyGen(1)
+    c.pool_reserve(2)
+    with pytest.raises(bce.BceError) as e:
+        c.EvalGates([(bce.AND, 0, 1, 2)])
+    assert e.value.code == bce.ERR_POOL
+    with pytest.raises(bce.BceError):
+        bce.BinFHEContext(bce.STD192, bce.GINX)   # 64-bit ring modulus: not built this round
