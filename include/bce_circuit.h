@@ -1,0 +1,123 @@
+/*
+ * bce_circuit.h -- C ABI over the host circuit runtime (C++ classes Circuit / Gate / Wire in
+ * openfhe-boolean-circuit-evaluator_amd/csrc/circuit.hpp), the caller side of the hot path.
+ *
+ * The C++ classes keep the reference's driver API (src/circuit.h:54-73, src/gate.h:50-80,
+ * src/wire.h:48-69) and its observable semantics -- one ASAP level of the DAG per manager /
+ * executor round, XOR = 2 NOT + 2 AND + 1 OR, the six per-op counters, plaintext /
+ * encrypted / verify modes -- but walk an indexed DAG and hand each ready frontier to
+ * bce_eval_gates() (include/bce_gpu.h) instead of spawning one OpenMP task per gate
+ * (src/circuit.cpp:698-710).  This header exposes them to non-C++ hosts (the Python tests
+ * and bench.py bind it with ctypes).
+ */
+#ifndef BCE_CIRCUIT_H
+#define BCE_CIRCUIT_H
+
+#include <stdint.h>
+
+#include "bce_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bce_circuit bce_circuit;
+
+typedef struct bce_circuit_info {
+    uint32_t n_gates;        /* all gates except LOADs (src/circuit.cpp allGates)      */
+    uint32_t n_input_gates;  /* LOADs                                                    */
+    uint32_t n_wires;        /* registers                                                */
+    uint32_t n_inputs;       /* number of input buses referenced (In1, In2)              */
+    uint32_t n_input_bits[2];
+    uint32_t n_output_bits;  /* max STORE index + 1 (single output bus)                  */
+    uint32_t n_levels;       /* Clock() rounds = ASAP levels incl. NOT and OUTPUT levels */
+    uint32_t n_sublaunches;  /* dependent bce_eval_gates launches per evaluation          */
+    uint32_t max_frontier;   /* widest sub-launch, in bootstraps                          */
+    uint64_t n_bootstraps;   /* per evaluation: AND=1, OR=1, XOR=3, NOT=0                 */
+} bce_circuit_info;
+
+typedef struct bce_circuit_stats {
+    double   total_ms;       /* "### Total time" of Clock(), src/circuit.cpp:565        */
+    double   management_ms;  /* _CircuitManager share                                    */
+    double   execution_ms;   /* _ExecuteGates share                                      */
+    uint64_t bootstraps;     /* executed by this rank in the last Clock()                */
+    uint32_t levels;
+    uint32_t sublaunches;
+    uint32_t verify_fixes;   /* "Bad <OP> fixing" events (verify mode)                   */
+    uint32_t exchanges;      /* multi-rank: number of allgather calls                    */
+    uint64_t exchanged_cts;  /* multi-rank: ciphertexts this rank contributed            */
+} bce_circuit_stats;
+
+/* allgather callback for multi-rank runs: every rank contributes `bytes` bytes found at the
+ * send buffer registered in bce_circuit_set_exchange and receives world*bytes in the
+ * registered receive buffer, rank-major.  on_device tells which buffer pair is meant. */
+typedef int (*bce_allgather_fn)(void* user, uint64_t bytes, int on_device);
+
+/* Circuit::Circuit(set, method), src/circuit.cpp:45-98, but the engine (keys included) is
+ * passed in so that several circuits can share one.  engine == NULL gives a
+ * plaintext-only circuit (host logic, no GPU needed); encrypted mode then fails loudly. */
+int bce_circuit_create(bce_ctx* engine, bce_circuit** out);
+void bce_circuit_destroy(bce_circuit*);
+const char* bce_circuit_last_error(const bce_circuit*);
+
+/* Circuit::ReadFile (assembler text format), src/circuit.cpp:102-366 */
+int bce_circuit_read_file(bce_circuit*, const char* path);
+/* direct Bristol netlist -> DAG (old: new_flag=0, "Bristol Fashion": new_flag=1) */
+int bce_circuit_read_bristol(bce_circuit*, const char* path, int new_flag);
+int bce_circuit_get_info(const bce_circuit*, bce_circuit_info* out);
+
+/* Circuit::Reset / setPlaintext / setEncrypted / setVerify, src/circuit.cpp:368-419,819-842 */
+int bce_circuit_reset(bce_circuit*);
+int bce_circuit_set_plaintext(bce_circuit*, int on);
+int bce_circuit_set_encrypted(bce_circuit*, int on);
+int bce_circuit_set_verify(bce_circuit*, int on);
+int bce_circuit_get_flags(const bce_circuit*, int* plaintext, int* encrypted, int* verify);
+/* 0: one bce_eval_gates call per gate through Gate::Evaluate (reference shape);
+ * 1 (default): one call per frontier stage */
+int bce_circuit_set_batched(bce_circuit*, int on);
+/* BinFHEContext::Encrypt output mode used by SetInput: BCE_FRESH (default) or BCE_BOOTSTRAPPED */
+int bce_circuit_set_encrypt_mode(bce_circuit*, int mode);
+
+/* K independent input sets evaluated in lock-step (call before SetInput) */
+int bce_circuit_set_instances(bce_circuit*, uint32_t k);
+/* Circuit::SetInput, src/circuit.cpp:455-530: bits = concatenation of the input buses,
+ * LSB first (Inputs[k][bit]); widths[k] = number of bits of bus k */
+int bce_circuit_set_input(bce_circuit*, uint32_t instance, const uint32_t* widths, uint32_t n_buses,
+                          const uint8_t* bits);
+/* Circuit::Clock, src/circuit.cpp:532-573 */
+int bce_circuit_clock(bce_circuit*);
+/* Outputs[0][bit] of one instance after Clock() */
+int bce_circuit_get_output(const bce_circuit*, uint32_t instance, uint8_t* bits);
+/* dumpGateCount counters: input, output, not, and, or, xor (src/circuit.cpp:866-873) */
+int bce_circuit_get_counts(const bce_circuit*, uint32_t out[6]);
+int bce_circuit_get_stats(const bce_circuit*, bce_circuit_stats* out);
+/* dumpNetList / dumpGates to stdout */
+int bce_circuit_dump(const bce_circuit*, int what);
+
+/* ---- multi-rank (one process per GPU) ---------------------------------------------- */
+/* shard_mode 0: instances are split contiguously over ranks (no exchange until the outputs);
+ * shard_mode 1: every level's gates are split over ranks and only ciphertexts whose
+ * fan-out crosses ranks are exchanged after the level.
+ * host_* / dev_* : buffers owned by the caller (e.g. torch tensors), `capacity` bytes for
+ * send and world*capacity for recv; dev_* may be NULL for plaintext-only runs. */
+int bce_circuit_set_exchange(bce_circuit*, uint32_t rank, uint32_t world, int shard_mode, bce_allgather_fn fn,
+                             void* user, void* host_send, void* host_recv, void* dev_send, void* dev_recv,
+                             uint64_t capacity);
+/* bytes one rank may contribute in the largest exchange of this circuit/instance count */
+uint64_t bce_circuit_exchange_capacity(const bce_circuit*, uint32_t world, int shard_mode, int encrypted);
+
+/* ---- Bristol front end (src/analyze.cpp:56, src/assemble.cpp:46) ------------------- */
+/* analyze_bristol + assemble_bristol: writes the assembler text file.  out_path NULL means
+ * "<input without extension>_FHE.out" like the reference. */
+int bce_assemble_bristol(const char* in_path, int new_flag, int gen_fan_flag, int debug_flag,
+                         const char* out_path, char* err, uint32_t err_len);
+
+/* ---- engine helpers used by the exchange path --------------------------------------- */
+/* pack pool rows (slots) into a dense device buffer [count][n+1] u32 and back */
+int bce_pool_gather(bce_ctx*, const uint32_t* slots, uint32_t count, void* dev_dst);
+int bce_pool_scatter(bce_ctx*, const uint32_t* slots, uint32_t count, const void* dev_src);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -262,3 +262,213 @@ class BinFHEContext:
         count = polys.size // self.N
         self._ck(self._L.bce_debug_ntt(self.h, _p(polys), count, 1 if inverse else 0))
         return polys
+
+
+# =====================================================================================
+# host circuit runtime (include/bce_circuit.h)
+# =====================================================================================
+class CircuitInfo(C.Structure):
+    _fields_ = [("n_gates", C.c_uint32), ("n_input_gates", C.c_uint32), ("n_wires", C.c_uint32),
+                ("n_inputs", C.c_uint32), ("n_input_bits", C.c_uint32 * 2), ("n_output_bits", C.c_uint32),
+                ("n_levels", C.c_uint32), ("n_sublaunches", C.c_uint32), ("max_frontier", C.c_uint32),
+                ("n_bootstraps", C.c_uint64)]
+
+
+class CircuitStats(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("management_ms", C.c_double), ("execution_ms", C.c_double),
+                ("bootstraps", C.c_uint64), ("levels", C.c_uint32), ("sublaunches", C.c_uint32),
+                ("verify_fixes", C.c_uint32), ("exchanges", C.c_uint32), ("exchanged_cts", C.c_uint64)]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_int)
+
+CIRCUIT_SYMBOLS = [
+    "bce_circuit_create", "bce_circuit_destroy", "bce_circuit_last_error", "bce_circuit_read_file",
+    "bce_circuit_read_bristol", "bce_circuit_get_info", "bce_circuit_reset", "bce_circuit_set_plaintext",
+    "bce_circuit_set_encrypted", "bce_circuit_set_verify", "bce_circuit_get_flags", "bce_circuit_set_batched",
+    "bce_circuit_set_encrypt_mode", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
+    "bce_circuit_get_output", "bce_circuit_get_counts", "bce_circuit_get_stats", "bce_circuit_dump",
+    "bce_circuit_set_exchange", "bce_circuit_exchange_capacity", "bce_assemble_bristol", "bce_pool_gather",
+    "bce_pool_scatter",
+]
+
+_circ_bound = False
+
+
+def _bind_circuit():
+    global _circ_bound
+    L = lib()
+    if _circ_bound:
+        return L
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    L.bce_circuit_create.argtypes = [vp, C.POINTER(vp)]
+    L.bce_circuit_destroy.argtypes = [vp]
+    L.bce_circuit_destroy.restype = None
+    L.bce_circuit_last_error.argtypes = [vp]
+    L.bce_circuit_last_error.restype = C.c_char_p
+    L.bce_circuit_read_file.argtypes = [vp, C.c_char_p]
+    L.bce_circuit_read_bristol.argtypes = [vp, C.c_char_p, i32]
+    L.bce_circuit_get_info.argtypes = [vp, C.POINTER(CircuitInfo)]
+    for name in ("reset", "clock"):
+        getattr(L, "bce_circuit_" + name).argtypes = [vp]
+    for name in ("set_plaintext", "set_encrypted", "set_verify", "set_batched", "set_encrypt_mode", "dump"):
+        getattr(L, "bce_circuit_" + name).argtypes = [vp, i32]
+    L.bce_circuit_get_flags.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.bce_circuit_set_instances.argtypes = [vp, u32]
+    L.bce_circuit_set_input.argtypes = [vp, u32, vp, u32, vp]
+    L.bce_circuit_get_output.argtypes = [vp, u32, vp]
+    L.bce_circuit_get_counts.argtypes = [vp, C.POINTER(u32 * 6)]
+    L.bce_circuit_get_stats.argtypes = [vp, C.POINTER(CircuitStats)]
+    L.bce_circuit_set_exchange.argtypes = [vp, u32, u32, i32, ALLGATHER_FN, vp, vp, vp, vp, vp, u64]
+    L.bce_circuit_exchange_capacity.argtypes = [vp, u32, i32, i32]
+    L.bce_circuit_exchange_capacity.restype = u64
+    L.bce_assemble_bristol.argtypes = [C.c_char_p, i32, i32, i32, C.c_char_p, C.c_char_p, u32]
+    L.bce_pool_gather.argtypes = [vp, vp, u32, vp]
+    L.bce_pool_scatter.argtypes = [vp, vp, u32, vp]
+    _circ_bound = True
+    return L
+
+
+def assemble_bristol(in_path, out_path=None, new_flag=False, gen_fan_flag=False, debug_flag=False):
+    """analyze_bristol + assemble_bristol (src/analyze.cpp:56, src/assemble.cpp:46)."""
+    L = _bind_circuit()
+    err = C.create_string_buffer(512)
+    rc = L.bce_assemble_bristol(in_path.encode(), int(new_flag), int(gen_fan_flag), int(debug_flag),
+                                out_path.encode() if out_path else None, err, 512)
+    if rc != OK:
+        raise BceError(rc, err.value.decode())
+
+
+# bit-order helpers of the reference harnesses (src/utils.cpp:49-89)
+def HexStr2UintVec(inhex):
+    """element 0 = LSB of the whole number: walk the string from its last character, nibble LSB-first"""
+    out = []
+    for ch in reversed(inhex):
+        v = int(ch, 16)
+        out.extend([(v >> b) & 1 for b in range(4)])
+    return out
+
+
+def BinStr2UintVec(inbin):
+    """element 0 = last character"""
+    return [int(ch) for ch in reversed(inbin)]
+
+
+class Circuit:
+    """Mirror of the reference's Circuit driver API (src/circuit.h:54-73)."""
+
+    def __init__(self, cc=None):
+        self._L = _bind_circuit()
+        self.cc = cc
+        h = C.c_void_p()
+        rc = self._L.bce_circuit_create(cc.h if cc is not None else None, C.byref(h))
+        if rc != OK:
+            raise BceError(rc, "bce_circuit_create failed")
+        self.h = h
+        self._keep = []
+
+    def _ck(self, rc):
+        if rc != OK:
+            raise BceError(rc, self._L.bce_circuit_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.bce_circuit_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ReadFile(self, path):
+        self._ck(self._L.bce_circuit_read_file(self.h, path.encode()))
+        return True
+
+    def ReadBristol(self, path, new_flag=False):
+        self._ck(self._L.bce_circuit_read_bristol(self.h, path.encode(), int(new_flag)))
+        return True
+
+    def info(self):
+        i = CircuitInfo()
+        self._ck(self._L.bce_circuit_get_info(self.h, C.byref(i)))
+        d = {k: getattr(i, k) for k, _ in CircuitInfo._fields_ if k != "n_input_bits"}
+        d["n_input_bits"] = [int(i.n_input_bits[0]), int(i.n_input_bits[1])]
+        return d
+
+    def Reset(self):
+        self._ck(self._L.bce_circuit_reset(self.h))
+
+    def setPlaintext(self, b):
+        self._ck(self._L.bce_circuit_set_plaintext(self.h, int(b)))
+
+    def setEncrypted(self, b):
+        self._ck(self._L.bce_circuit_set_encrypted(self.h, int(b)))
+
+    def setVerify(self, b):
+        self._ck(self._L.bce_circuit_set_verify(self.h, int(b)))
+
+    def _flags(self):
+        p, e, v = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._L.bce_circuit_get_flags(self.h, C.byref(p), C.byref(e), C.byref(v)))
+        return bool(p.value), bool(e.value), bool(v.value)
+
+    def getPlaintext(self):
+        return self._flags()[0]
+
+    def getEncrypted(self):
+        return self._flags()[1]
+
+    def getVerify(self):
+        return self._flags()[2]
+
+    def setBatched(self, b):
+        self._ck(self._L.bce_circuit_set_batched(self.h, int(b)))
+
+    def setEncryptMode(self, mode):
+        self._ck(self._L.bce_circuit_set_encrypt_mode(self.h, int(mode)))
+
+    def setInstances(self, k):
+        self._ck(self._L.bce_circuit_set_instances(self.h, int(k)))
+
+    def SetInput(self, inputs, instance=0):
+        """inputs[k][bit], LSB = index 0 (the reference's Inputs type)"""
+        widths = np.array([len(b) for b in inputs], dtype=np.uint32)
+        bits = np.array([v for b in inputs for v in b], dtype=np.uint8)
+        if bits.size == 0:
+            bits = np.zeros(1, dtype=np.uint8)
+        self._ck(self._L.bce_circuit_set_input(self.h, int(instance), _p(widths), len(inputs), _p(bits)))
+
+    def Clock(self, instance=0):
+        self._ck(self._L.bce_circuit_clock(self.h))
+        return self.Outputs(instance)
+
+    def Outputs(self, instance=0):
+        n = self.info()["n_output_bits"]
+        out = np.zeros(max(n, 1), dtype=np.uint8)
+        self._ck(self._L.bce_circuit_get_output(self.h, int(instance), _p(out)))
+        return [[int(v) for v in out[:n]]]
+
+    def counts(self):
+        c = (C.c_uint32 * 6)()
+        self._ck(self._L.bce_circuit_get_counts(self.h, C.byref(c)))
+        return dict(zip(["input", "output", "not", "and", "or", "xor"], [int(v) for v in c]))
+
+    def stats(self):
+        s = CircuitStats()
+        self._ck(self._L.bce_circuit_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in CircuitStats._fields_}
+
+    def dumpGateCount(self):
+        self._ck(self._L.bce_circuit_dump(self.h, 2))
+
+    def exchange_capacity(self, world, shard_mode, encrypted):
+        return int(self._L.bce_circuit_exchange_capacity(self.h, world, shard_mode, int(encrypted)))
+
+    def set_exchange(self, rank, world, shard_mode, fn, host_send, host_recv, dev_send, dev_recv, capacity):
+        """fn(bytes, on_device) -> 0 on success; buffers are raw addresses (e.g. tensor.data_ptr())"""
+        cb = ALLGATHER_FN(lambda user, nbytes, on_dev: int(fn(int(nbytes), int(on_dev))))
+        self._keep.append(cb)
+        self._ck(self._L.bce_circuit_set_exchange(self.h, rank, world, shard_mode, cb, None, host_send, host_recv,
+                                                  dev_send, dev_recv, capacity))

@@ -1,0 +1,791 @@
+// circuit.cpp -- host DAG walker (see circuit.hpp).  Behavioural contract: SURVEY.md App. F.
+#include "circuit.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+
+#include "bristol.hpp"
+
+namespace bce {
+
+namespace {
+using Clock_t = std::chrono::steady_clock;
+double ms_since(Clock_t::time_point t0) { return std::chrono::duration<double, std::milli>(Clock_t::now() - t0).count(); }
+bool contains(const std::string& s, const char* sub) { return s.find(sub) != std::string::npos; }
+const char* op_name(GateEnum op) {
+    switch (op) {
+        case GateEnum::INPUT: return "INPUT";
+        case GateEnum::OUTPUT: return "OUTPUT";
+        case GateEnum::NOT: return "NOT";
+        case GateEnum::AND: return "AND";
+        case GateEnum::OR: return "OR";
+        case GateEnum::XOR: return "XOR";
+        default: return "?";
+    }
+}
+uint32_t gate_weight(GateEnum op) {  // bootstraps per gate (src/gate.cpp:133,172,200-202)
+    switch (op) {
+        case GateEnum::AND: case GateEnum::OR: return 1;
+        case GateEnum::XOR: return 3;
+        default: return 0;
+    }
+}
+}  // namespace
+
+// ---- Wire -------------------------------------------------------------------------------
+void Wire::updateFanoutGates(const std::string& gateToRemove) {
+    auto it = std::find(fanoutGates.begin(), fanoutGates.end(), gateToRemove);
+    if (it == fanoutGates.end()) {
+        std::cerr << "error can't find " << gateToRemove << " in fanout of wire " << name << std::endl;
+        return;
+    }
+    fanoutGates.erase(it);
+}
+
+// ---- Gate -------------------------------------------------------------------------------
+static void gate_ck(const GateEvalParams& gep, int rc, const std::string& name) {
+    if (rc != BCE_OK) throw std::runtime_error("gate " + name + ": " + bce_last_error(gep.cc));
+}
+
+// verify-and-fix (src/gate.cpp:113-120,153-160,174-181,206-213)
+static void verify_fix(const GateEvalParams& gep, const char* opn, CipherText slot, unsigned expect, bool fix,
+                       const std::string& name) {
+    uint8_t res = 0;
+    gate_ck(gep, bce_decrypt_bits(gep.cc, &slot, 1, &res), name);
+    if (res != expect) {
+        std::cerr << "Bad " << opn << " fixing" << std::endl;
+        if (gep.fixes) ++*gep.fixes;
+        if (fix) {
+            uint8_t bit = (uint8_t)expect;
+            uint64_t idx = gep.enc_counter ? (*gep.enc_counter)++ : 0;
+            gate_ck(gep, bce_encrypt_bits(gep.cc, &bit, &slot, 1, idx, BCE_FRESH), name);
+        }
+    }
+}
+
+void Gate::Evaluate(const GateEvalParams& gep) {
+    bool all_ready = true;
+    for (bool r : ready) all_ready = all_ready && r;
+    if (!all_ready) std::cerr << "error, executing gate " << name << " but inputs not ready!" << std::endl;
+    const bool pt = gep.plaintext_flag, en = gep.encrypted_flag, vf = gep.verify_flag;
+    if (en && !gep.cc) throw std::runtime_error("gate " + name + ": encrypted evaluation needs an engine");
+    auto enc_dst = [&]() -> CipherText {
+        if (encout.empty() || encout[0] == kNoCipherText) throw std::runtime_error("gate " + name + ": no destination slot");
+        return encout[0];
+    };
+    switch (op) {
+        case GateEnum::INPUT:
+            std::cerr << "error executing input should not happen" << std::endl;
+            break;
+        case GateEnum::OUTPUT:
+            if (pt) { plainout.resize(1); plainout[0] = plainin[0]; }
+            if (en) {
+                encout.resize(1);
+                encout[0] = encin[0];  // copy of the handle (src/gate.cpp:90-94)
+                if (vf) verify_fix(gep, "OUTPUT", encout[0], plainout[0], false, name);
+            }
+            break;
+        case GateEnum::NOT:
+            if (pt) { plainout.resize(1); plainout[0] = !plainin[0]; }
+            if (en) {
+                bce_gate_desc d{BCE_OP_NOT, encin[0], encin[0], enc_dst(), 0, 0};
+                gate_ck(gep, bce_eval_gates(gep.cc, 1, &d), name);
+                if (vf) verify_fix(gep, "NOT", encout[0], plainout[0], true, name);
+            }
+            break;
+        case GateEnum::AND:
+        case GateEnum::OR:
+            if (pt) {
+                plainout.resize(1);
+                plainout[0] = (op == GateEnum::AND) ? (plainin[0] && plainin[1]) : (plainin[0] || plainin[1]);
+            }
+            if (en) {
+                // The reference retries AND after a throw because OpenFHE rejects ct1 == ct2
+                // (src/gate.cpp:131-152); the engine computes on values, so equal handles are legal.
+                bce_gate_desc d{(uint32_t)(op == GateEnum::AND ? BCE_AND : BCE_OR), encin[0], encin[1], enc_dst(), 0, 0};
+                gate_ck(gep, bce_eval_gates(gep.cc, 1, &d), name);
+                if (vf) verify_fix(gep, op == GateEnum::AND ? "AND" : "OR", encout[0], plainout[0], true, name);
+            }
+            break;
+        case GateEnum::XOR:
+            if (pt) { plainout.resize(1); plainout[0] = plainin[0] ^ plainin[1]; }
+            if (en) {
+                // (a AND !b) OR (!a AND b), src/gate.cpp:198-202; the NOTs are folded into the prep
+                if (tmp.size() < 2) throw std::runtime_error("gate " + name + ": XOR needs two scratch slots");
+                bce_gate_desc a[2] = {{BCE_AND, encin[0], encin[1], tmp[0], 0, 1}, {BCE_AND, encin[0], encin[1], tmp[1], 1, 0}};
+                gate_ck(gep, bce_eval_gates(gep.cc, 2, a), name);
+                bce_gate_desc o{BCE_OR, tmp[0], tmp[1], enc_dst(), 0, 0};
+                gate_ck(gep, bce_eval_gates(gep.cc, 1, &o), name);
+                if (vf) verify_fix(gep, "XOR", encout[0], plainout[0], true, name);
+            }
+            break;
+        case GateEnum::DFF: std::cerr << "remember to write DFF" << std::endl; break;
+        case GateEnum::LUT3: std::cerr << "remember to write LUT3" << std::endl; break;
+        case GateEnum::LUT4: std::cerr << "remember to write LUT4" << std::endl; break;
+        default: std::cerr << "bad gate eval" << std::endl;
+    }
+}
+
+// ---- Circuit ------------------------------------------------------------------------------
+Circuit::Circuit(int set, int method) {
+    std::cout << "Generating crypto context" << std::endl;
+    if (set == BCE_TOY) {
+        std::cout << "*************************\nWARNING TOY Security used\n*************************" << std::endl;
+    } else if (set == BCE_STD128_OPT) {
+        std::cout << "STD 128 Optimized Security used" << std::endl;
+    } else {
+        throw std::invalid_argument("Error Bad security");  // the reference exits here (src/circuit.cpp:75-78)
+    }
+    if (method == BCE_AP) std::cout << "AP used" << std::endl;
+    else if (method == BCE_GINX) std::cout << "GINX used" << std::endl;
+    else throw std::invalid_argument("Error Bad method");
+    int rc = bce_ctx_create(set, method, 0, &cc);
+    if (rc != BCE_OK) throw std::runtime_error(std::string("GenerateBinFHEContext: ") + bce_last_error(nullptr));
+    owns_engine_ = true;
+    std::cout << "Generating crypto keys" << std::endl;
+    uint8_t seed[32] = {0xED, 0xE5, 0x0F};
+    rc = bce_keygen(cc, seed);
+    if (rc != BCE_OK) {
+        std::string m = bce_last_error(cc);
+        bce_ctx_destroy(cc);
+        throw std::runtime_error("BTKeyGen: " + m);
+    }
+    std::cout << "Done" << std::endl;
+    gep.cc = cc;
+    gep.enc_counter = &enc_counter_;
+    gep.fixes = &stats_.verify_fixes;
+}
+
+Circuit::Circuit(bce_ctx* engine) : cc(engine) {
+    gep.cc = cc;
+    gep.enc_counter = &enc_counter_;
+    gep.fixes = &stats_.verify_fixes;
+    quiet_ = true;
+}
+
+Circuit::~Circuit() {
+    if (owns_engine_ && cc) bce_ctx_destroy(cc);
+}
+
+void Circuit::requireEngine(const char* what) const {
+    if (!cc) throw std::runtime_error(std::string(what) + ": this circuit has no engine (plaintext-only); encrypted mode needs the HIP engine");
+}
+void Circuit::ck(int rc, const char* what) const {
+    if (rc != BCE_OK) throw std::runtime_error(std::string(what) + ": " + bce_last_error(cc));
+}
+
+int Circuit::addWire(uint32_t reg) {
+    auto it = wire_of_reg_.find(reg);
+    if (it != wire_of_reg_.end()) return it->second;
+    int id = (int)wire_names_.size();
+    wire_of_reg_[reg] = id;
+    wire_names_.push_back("R:" + std::to_string(reg));
+    return id;
+}
+
+int Circuit::wireOf(uint32_t reg, const char* what, unsigned lineNo) const {
+    auto it = wire_of_reg_.find(reg);
+    if (it == wire_of_reg_.end())
+        throw std::runtime_error(std::string(what) + " parse error line " + std::to_string(lineNo) + ": register R" + std::to_string(reg) + " used before it is defined");
+    return it->second;
+}
+
+bool Circuit::ReadFile(const std::string& inFname) {
+    if (!quiet_) std::cout << "Loading circuit description " << inFname << std::endl;
+    std::ifstream in(inFname);
+    if (!in) throw std::runtime_error("error opening file " + inFname);
+    inputGates.clear(); allGates.clear(); wire_names_.clear(); wire_of_reg_.clear();
+    unsigned lineNo = 0, gateNo = 0, max_out = 0;
+    bool any_out = false;
+    std::string t;
+    n_buses_ = 0; n_in_bits_[0] = n_in_bits_[1] = 0;
+    while (std::getline(in, t)) {
+        ++lineNo;
+        if (!quiet_ && lineNo % 100 == 0) std::cout << "\r loading line " << lineNo << std::flush;
+        if (!t.empty() && t[0] == '#') continue;
+        unsigned n1 = 0, n2 = 0, n3 = 0;
+        auto two_in = [&](const char* fmt, const char* what, GateEnum op) {
+            if (std::sscanf(t.c_str(), fmt, &n1, &n2, &n3) != 3) throw std::runtime_error(std::string(what) + " parse error line " + std::to_string(lineNo));
+            GateRec g{op, 2, {wireOf(n2, what, lineNo), wireOf(n3, what, lineNo)}, -1, -1, std::string(what) + ":" + std::to_string(gateNo++)};
+            g.out = addWire(n1);
+            allGates.push_back(g);
+        };
+        // dispatch order of the reference reader (src/circuit.cpp:144,171,199,223,246,270,292)
+        if (contains(t, "LOAD")) {
+            if (std::sscanf(t.c_str(), "R%u = LOAD(In%u, %u)", &n1, &n2, &n3) != 3 || n2 < 1 || n2 > 2)
+                throw std::runtime_error("LOAD parse error line " + std::to_string(lineNo));
+            LoadRec l{n2 - 1, n3, addWire(n1), "INPUT:" + std::to_string(gateNo++)};
+            n_buses_ = std::max(n_buses_, n2);
+            n_in_bits_[n2 - 1] = std::max(n_in_bits_[n2 - 1], n3 + 1);
+            inputGates.push_back(l);
+        } else if (contains(t, "STORE")) {
+            if (std::sscanf(t.c_str(), "Out%u = STORE(R%u)", &n1, &n2) != 2) throw std::runtime_error("STORE parse error line " + std::to_string(lineNo));
+            GateRec g{GateEnum::OUTPUT, 1, {wireOf(n2, "STORE", lineNo), -1}, -1, (int)n1, "OUTPUT:" + std::to_string(gateNo++)};
+            allGates.push_back(g);
+            max_out = std::max(max_out, n1);
+            any_out = true;
+        } else if (contains(t, "NOT")) {
+            if (std::sscanf(t.c_str(), "R%u = NOT(R%u)", &n1, &n2) != 2) throw std::runtime_error("NOT parse error line " + std::to_string(lineNo));
+            GateRec g{GateEnum::NOT, 1, {wireOf(n2, "NOT", lineNo), -1}, -1, -1, "NOT:" + std::to_string(gateNo++)};
+            g.out = addWire(n1);
+            allGates.push_back(g);
+        } else if (contains(t, "AND")) {
+            two_in("R%u = AND(R%u, R%u)", "AND", GateEnum::AND);
+        } else if (contains(t, " OR")) {
+            two_in("R%u = OR(R%u, R%u)", "OR", GateEnum::OR);
+        } else if (contains(t, "XOR")) {
+            two_in("R%u = XOR(R%u, R%u)", "XOR", GateEnum::XOR);
+        } else if (contains(t, "BOOT")) {
+            // no-op
+        }
+    }
+    n_outputs = 1;
+    n_output_bits.assign(1, any_out ? max_out + 1 : 0);
+    if (!quiet_) {
+        std::cout << std::endl << "generating output nbits " << n_output_bits[0] << std::endl;
+        std::cout << "generating netlist" << std::endl;
+    }
+    finalizeNetlist();
+    if (!quiet_) std::cout << "Done" << std::endl;
+    return true;
+}
+
+bool Circuit::ReadBristol(const std::string& path, bool new_flag) {
+    Analysis A = analyze_bristol(path, false, new_flag, true);
+    const Variable& v = A.variables;
+    const Function& f = A.functions;
+    inputGates.clear(); allGates.clear(); wire_names_.clear(); wire_of_reg_.clear();
+    unsigned gateNo = 0;
+    // same register numbering as the assembler: inputs first, then one register per gate
+    std::vector<int> node_wire(v.n_tot, -1);
+    uint32_t reg = 0;
+    for (unsigned b = 0; b < v.n_in1_bits; ++b) { node_wire[b] = addWire(reg++); inputGates.push_back({0, b, node_wire[b], "INPUT:" + std::to_string(gateNo++)}); }
+    for (unsigned b = 0; b < v.n_in2_bits; ++b) { node_wire[v.n_in1_bits + b] = addWire(reg++); inputGates.push_back({1, b, node_wire[v.n_in1_bits + b], "INPUT:" + std::to_string(gateNo++)}); }
+    n_buses_ = v.n_in2_bits ? 2 : 1;
+    n_in_bits_[0] = v.n_in1_bits; n_in_bits_[1] = v.n_in2_bits;
+    for (size_t i = 0; i < f.call_list.size(); ++i) {
+        const std::string& op = f.call_list[i];
+        GateRec g{};
+        g.in[0] = g.in[1] = -1; g.out_bit = -1;
+        const auto& il = f.in_list[i];
+        for (unsigned w : il) if (node_wire[w] < 0) throw std::runtime_error("ReadBristol: gate " + std::to_string(i) + " uses undefined wire");
+        if (op == "XOR" || op == "AND") {
+            if (il.size() != 2) throw std::runtime_error("ReadBristol: bad arity");
+            g.op = op == "XOR" ? GateEnum::XOR : GateEnum::AND; g.nin = 2; g.in[0] = node_wire[il[0]]; g.in[1] = node_wire[il[1]];
+        } else if (op == "NOT") {
+            g.op = GateEnum::NOT; g.nin = 1; g.in[0] = node_wire[il.at(0)];
+        } else {
+            throw std::runtime_error("ReadBristol: unsupported op " + op + " at gate " + std::to_string(i));
+        }
+        g.name = std::string(op_name(g.op)) + ":" + std::to_string(gateNo++);
+        g.out = addWire(reg++);
+        node_wire[f.out_list[i].at(0)] = g.out;
+        allGates.push_back(g);
+    }
+    for (unsigned o = 0; o < v.n_out1_bits; ++o) {
+        int w = node_wire[v.n_tot - v.n_out1_bits + o];
+        if (w < 0) throw std::runtime_error("ReadBristol: output node never driven");
+        allGates.push_back(GateRec{GateEnum::OUTPUT, 1, {w, -1}, -1, (int)o, "OUTPUT:" + std::to_string(gateNo++)});
+    }
+    n_outputs = 1;
+    n_output_bits.assign(1, v.n_out1_bits);
+    finalizeNetlist();
+    return true;
+}
+
+// CSR fan-out + static ASAP levelisation (what _CircuitManager discovers round by round)
+void Circuit::finalizeNetlist() {
+    const size_t W = wire_names_.size(), G = allGates.size();
+    fan_off_.assign(W + 1, 0);
+    for (const auto& g : allGates) for (int k = 0; k < g.nin; ++k) ++fan_off_[g.in[k] + 1];
+    for (size_t w = 0; w < W; ++w) fan_off_[w + 1] += fan_off_[w];
+    fan_gate_.assign(fan_off_[W], 0);
+    std::vector<uint32_t> pos(fan_off_.begin(), fan_off_.end() - 1);
+    for (size_t gi = 0; gi < G; ++gi) for (int k = 0; k < allGates[gi].nin; ++k) fan_gate_[pos[allGates[gi].in[k]]++] = (uint32_t)gi;
+
+    levels_.clear();
+    gate_level_.assign(G, -1);
+    std::vector<int> ready(G, 0), active;
+    for (const auto& l : inputGates) active.push_back(l.wire);
+    max_level_xor_ = 0;
+    while (!active.empty()) {
+        Level L;
+        for (int w : active)
+            for (uint32_t e = fan_off_[w]; e < fan_off_[w + 1]; ++e) {
+                uint32_t gi = fan_gate_[e];
+                if (++ready[gi] == allGates[gi].nin) L.gates.push_back((int)gi);
+            }
+        if (L.gates.empty()) break;
+        std::sort(L.gates.begin(), L.gates.end());
+        active.clear();
+        for (int gi : L.gates) {
+            gate_level_[gi] = (int)levels_.size();
+            if (allGates[gi].op == GateEnum::XOR) ++L.n_xor;
+            if (allGates[gi].out >= 0) active.push_back(allGates[gi].out);
+        }
+        max_level_xor_ = std::max(max_level_xor_, L.n_xor);
+        levels_.push_back(std::move(L));
+    }
+    stride_ = (uint32_t)W + 2 * max_level_xor_;
+    buildShardPlan();
+    Reset();
+}
+
+void Circuit::Reset() {
+    n_input_gates = n_output_gates = n_and_gates = n_or_gates = n_xor_gates = n_not_gates = 0;
+    plaintext_flag = encrypted_flag = verify_flag = false;  // gep's copies are left alone, like the reference
+    done = false;
+    inputs_set_ = false;
+    ++epoch_;
+    plain_.assign(instances_, std::vector<uint8_t>(wire_names_.size(), 0));
+    circuitOut.assign(instances_, std::vector<uint8_t>(n_output_bits.empty() ? 0 : n_output_bits[0], 0));
+    stats_ = bce_circuit_stats{};
+}
+
+void Circuit::setVerify(bool b) {
+    verify_flag = gep.verify_flag = b;
+    if (b) { setPlaintext(true); setEncrypted(true); }
+}
+
+void Circuit::setInstances(unsigned k) {
+    if (k == 0) throw std::invalid_argument("setInstances: need at least one instance");
+    instances_ = k;
+    plain_.assign(instances_, std::vector<uint8_t>(wire_names_.size(), 0));
+    circuitOut.assign(instances_, std::vector<uint8_t>(n_output_bits.empty() ? 0 : n_output_bits[0], 0));
+    buildShardPlan();
+}
+
+void Circuit::instanceRange(unsigned& lo, unsigned& hi) const {
+    lo = 0; hi = instances_;
+    if (world_ > 1 && shard_mode_ == 0) {
+        unsigned per = instances_ / world_;
+        lo = rank_ * per; hi = lo + per;
+    }
+}
+
+void Circuit::SetInput(const Inputs& input, bool verbose) { SetInput(0, input, verbose); }
+
+void Circuit::SetInput(unsigned inst, const Inputs& input, bool verbose) {
+    if (inst >= instances_) throw std::out_of_range("SetInput: instance out of range");
+    size_t total_bits = 0;
+    for (size_t k = 0; k < input.size(); ++k) {
+        if (verbose) std::cout << "setting input " << k << " size " << input[k].size() << std::endl;
+        total_bits += input[k].size();
+    }
+    if (verbose) std::cout << "set input total of " << input.size() << " inputs" << std::endl;
+    unsigned lo, hi;
+    instanceRange(lo, hi);
+    const bool mine = inst >= lo && inst < hi;
+    std::vector<uint8_t> bits;
+    std::vector<uint32_t> slots;
+    n_input_gates = 0;
+    for (const auto& l : inputGates) {
+        if (l.bus >= input.size() || l.bit >= input[l.bus].size())
+            throw std::out_of_range("SetInput: " + l.name + " reads In" + std::to_string(l.bus + 1) + " bit " + std::to_string(l.bit) + " which was not supplied");
+        uint8_t v = input[l.bus][l.bit] ? 1 : 0;
+        ++n_input_gates;
+        plain_[inst][l.wire] = v;
+        bits.push_back(v);
+        slots.push_back(inst * stride_ + (uint32_t)l.wire);
+    }
+    if (total_bits != inputGates.size())
+        std::cerr << "error: total_inputs: " << total_bits << " #used: " << inputGates.size() << std::endl;
+    else if (verbose)
+        std::cout << "input confirmed" << std::endl;
+    if (encrypted_flag && mine) {  // encrypted mode must be on at call time (src/circuit.cpp:505-507)
+        requireEngine("SetInput");
+        ck(bce_pool_reserve(cc, instances_ * stride_), "SetInput(pool)");
+        // stream index = (evaluation epoch, instance, input position): every rank draws the same ciphertexts
+        uint64_t base = ((epoch_ & 0xFFFFFull) << 44) | ((uint64_t)inst << 24);
+        ck(bce_encrypt_bits(cc, bits.data(), slots.data(), (uint32_t)slots.size(), base, encrypt_mode_), "SetInput(Encrypt)");
+    }
+    inputs_set_ = true;
+}
+
+// ---- sharding plan --------------------------------------------------------------------------
+void Circuit::buildShardPlan() {
+    owner_.clear();
+    xwires_.clear();
+    if (world_ <= 1 || shard_mode_ != 1) return;
+    const size_t Lc = levels_.size();
+    owner_.resize(Lc);
+    std::vector<uint8_t> gate_owner(allGates.size(), 0xFF);  // 0xFF = everyone (OUTPUT)
+    for (size_t l = 0; l < Lc; ++l) {
+        const auto& gl = levels_[l].gates;
+        uint64_t total = 0;
+        for (int gi : gl) total += 4 * gate_weight(allGates[gi].op) + 1;  // NOT/OUTPUT weigh 1/4 bootstrap
+        uint64_t cum = 0;
+        owner_[l].resize(gl.size());
+        for (size_t k = 0; k < gl.size(); ++k) {
+            const auto& g = allGates[gl[k]];
+            uint8_t o = (uint8_t)std::min<uint64_t>(world_ - 1, cum * world_ / std::max<uint64_t>(total, 1));
+            cum += 4 * gate_weight(g.op) + 1;
+            if (g.op == GateEnum::OUTPUT) o = 0xFF;
+            owner_[l][k] = o;
+            gate_owner[gl[k]] = o;
+        }
+    }
+    xwires_.assign(Lc, std::vector<std::vector<int>>(world_));
+    for (size_t l = 0; l < Lc; ++l) {
+        const auto& gl = levels_[l].gates;
+        for (size_t k = 0; k < gl.size(); ++k) {
+            const auto& g = allGates[gl[k]];
+            if (g.out < 0) continue;
+            const uint8_t o = owner_[l][k];
+            bool cross = false;
+            for (uint32_t e = fan_off_[g.out]; e < fan_off_[g.out + 1] && !cross; ++e) cross = gate_owner[fan_gate_[e]] != o;
+            if (cross) xwires_[l][o].push_back(g.out);
+        }
+    }
+}
+
+uint64_t Circuit::exchangeCapacity(uint32_t world, int shard_mode, bool encrypted) const {
+    uint64_t W = 4;
+    if (encrypted && cc) { uint64_t p[BCE_P_COUNT]; bce_get_params(cc, p); W = 4 * (p[BCE_P_n] + 1); }
+    const uint64_t nout = n_output_bits.empty() ? 0 : n_output_bits[0];
+    if (world <= 1) return 0;
+    if (shard_mode == 0) return std::max<uint64_t>(64, (uint64_t)(instances_ / world) * nout);
+    // mode 1: widest per-rank publication over all levels (plan must be built for this world)
+    uint64_t widest = 0;
+    for (const auto& lv : xwires_) for (const auto& r : lv) widest = std::max<uint64_t>(widest, r.size());
+    if (xwires_.empty()) for (const auto& lv : levels_) widest = std::max<uint64_t>(widest, lv.gates.size());
+    return std::max<uint64_t>(64, widest * instances_ * (encrypted ? W : 1));
+}
+
+void Circuit::setExchange(uint32_t rank, uint32_t world, int shard_mode, bce_allgather_fn fn, void* user, void* host_send,
+                          void* host_recv, void* dev_send, void* dev_recv, uint64_t capacity) {
+    if (world == 0 || rank >= world) throw std::invalid_argument("setExchange: bad rank/world");
+    if (world > 1 && !fn) throw std::invalid_argument("setExchange: allgather callback missing");
+    if (world > 1 && shard_mode == 0 && instances_ % world) throw std::invalid_argument("setExchange: instance sharding needs instances divisible by world");
+    if (world > 250) throw std::invalid_argument("setExchange: world too large");
+    rank_ = rank; world_ = world; shard_mode_ = shard_mode; xfn_ = fn; xuser_ = user;
+    host_send_ = host_send; host_recv_ = host_recv; dev_send_ = dev_send; dev_recv_ = dev_recv; xcap_ = capacity;
+    buildShardPlan();
+}
+
+// after a level: publish wires whose consumers sit on other ranks (shard_mode 1)
+void Circuit::exchangeLevel(size_t level) {
+    if (world_ <= 1 || shard_mode_ != 1) return;
+    size_t widest = 0;
+    for (uint32_t r = 0; r < world_; ++r) widest = std::max(widest, xwires_[level][r].size());
+    if (widest == 0) return;
+    const auto& mine = xwires_[level][rank_];
+    const unsigned K = instances_;
+    if (plaintext_flag) {
+        const uint64_t bytes = (uint64_t)widest * K;
+        if (bytes > xcap_ || !host_send_ || !host_recv_) throw std::runtime_error("exchange: host buffers too small");
+        uint8_t* s = (uint8_t*)host_send_;
+        std::memset(s, 0, bytes);
+        for (unsigned i = 0; i < K; ++i) for (size_t k = 0; k < mine.size(); ++k) s[i * widest + k] = plain_[i][mine[k]];
+        if (xfn_(xuser_, bytes, 0) != 0) throw std::runtime_error("exchange: allgather callback failed");
+        const uint8_t* rcv = (const uint8_t*)host_recv_;
+        for (uint32_t r = 0; r < world_; ++r) {
+            if (r == rank_) continue;
+            const auto& theirs = xwires_[level][r];
+            for (unsigned i = 0; i < K; ++i) for (size_t k = 0; k < theirs.size(); ++k) plain_[i][theirs[k]] = rcv[(uint64_t)r * bytes + i * widest + k];
+        }
+        ++stats_.exchanges;
+    }
+    if (encrypted_flag) {
+        uint64_t p[BCE_P_COUNT];
+        bce_get_params(cc, p);
+        const uint64_t W = 4 * (p[BCE_P_n] + 1);
+        const uint64_t bytes = (uint64_t)widest * K * W;
+        if (bytes > xcap_ || !dev_send_ || !dev_recv_) throw std::runtime_error("exchange: device buffers too small");
+        std::vector<uint32_t> slots;
+        for (unsigned i = 0; i < K; ++i) for (size_t k = 0; k < widest; ++k) slots.push_back(i * stride_ + (uint32_t)(k < mine.size() ? mine[k] : (mine.empty() ? 0 : mine[0])));
+        ck(bce_pool_gather(cc, slots.data(), (uint32_t)slots.size(), dev_send_), "exchange(gather)");
+        ck(bce_synchronize(cc), "exchange(sync)");
+        if (xfn_(xuser_, bytes, 1) != 0) throw std::runtime_error("exchange: allgather callback failed");
+        for (uint32_t r = 0; r < world_; ++r) {
+            if (r == rank_) continue;
+            const auto& theirs = xwires_[level][r];
+            if (theirs.empty()) continue;
+            // rows [i][k<theirs.size()] of rank r's block
+            for (unsigned i = 0; i < K; ++i) {
+                slots.clear();
+                for (size_t k = 0; k < theirs.size(); ++k) slots.push_back(i * stride_ + (uint32_t)theirs[k]);
+                const char* src = (const char*)dev_recv_ + (uint64_t)r * bytes + (uint64_t)i * widest * W;
+                ck(bce_pool_scatter(cc, slots.data(), (uint32_t)slots.size(), src), "exchange(scatter)");
+            }
+        }
+        ++stats_.exchanges;
+        stats_.exchanged_cts += (uint64_t)mine.size() * K;
+    }
+}
+
+// shard_mode 0: every rank ends with the outputs of all instances
+void Circuit::gatherOutputs() {
+    if (world_ <= 1 || shard_mode_ != 0) return;
+    const uint64_t nout = n_output_bits[0];
+    unsigned lo, hi;
+    instanceRange(lo, hi);
+    const uint64_t bytes = (uint64_t)(hi - lo) * nout;
+    if (bytes == 0) return;
+    if (bytes > xcap_ || !host_send_ || !host_recv_) throw std::runtime_error("gatherOutputs: host buffers too small");
+    uint8_t* s = (uint8_t*)host_send_;
+    for (unsigned i = lo; i < hi; ++i) std::memcpy(s + (uint64_t)(i - lo) * nout, circuitOut[i].data(), nout);
+    if (xfn_(xuser_, bytes, 0) != 0) throw std::runtime_error("gatherOutputs: allgather callback failed");
+    const uint8_t* rcv = (const uint8_t*)host_recv_;
+    const unsigned per = hi - lo;
+    for (uint32_t r = 0; r < world_; ++r)
+        for (unsigned k = 0; k < per; ++k) std::memcpy(circuitOut[r * per + k].data(), rcv + (uint64_t)r * bytes + (uint64_t)k * nout, nout);
+    ++stats_.exchanges;
+}
+
+// ---- Clock -------------------------------------------------------------------------------------
+void Circuit::managerRound(size_t) {
+    // Readiness was resolved once in finalizeNetlist(); the per-round work the reference does here
+    // (src/circuit.cpp:575-683: scanning waitingGates for every active wire) has no counterpart.
+}
+
+void Circuit::executeRound(size_t level) {
+    const Level& L = levels_[level];
+    unsigned lo, hi;
+    instanceRange(lo, hi);
+    const bool sharded_gates = world_ > 1 && shard_mode_ == 1;
+    auto mine = [&](size_t k) { return !sharded_gates || owner_[level][k] == 0xFF || owner_[level][k] == rank_; };
+
+    if (plaintext_flag) {
+        for (unsigned i = lo; i < hi; ++i) {
+            auto& pv = plain_[i];
+            for (size_t k = 0; k < L.gates.size(); ++k) {
+                if (!mine(k)) continue;
+                const GateRec& g = allGates[L.gates[k]];
+                switch (g.op) {
+                    case GateEnum::NOT: pv[g.out] = !pv[g.in[0]]; break;
+                    case GateEnum::AND: pv[g.out] = pv[g.in[0]] && pv[g.in[1]]; break;
+                    case GateEnum::OR: pv[g.out] = pv[g.in[0]] || pv[g.in[1]]; break;
+                    case GateEnum::XOR: pv[g.out] = pv[g.in[0]] ^ pv[g.in[1]]; break;
+                    default: break;
+                }
+            }
+        }
+    }
+    if (encrypted_flag) {
+        requireEngine("Clock");
+        const uint32_t tmp0 = (uint32_t)wire_names_.size();
+        if (batched_) {
+            // stage A: AND / OR gates and the two ANDs of every XOR; stage B: the OR of every XOR
+            std::vector<bce_gate_desc> A, B;
+            uint32_t x = 0;
+            for (size_t k = 0; k < L.gates.size(); ++k) {
+                const GateRec& g = allGates[L.gates[k]];
+                const bool me = mine(k);
+                if (g.op == GateEnum::XOR) {
+                    const uint32_t t1 = tmp0 + 2 * x, t2 = t1 + 1;
+                    ++x;
+                    if (!me) continue;
+                    A.push_back({BCE_AND, (uint32_t)g.in[0], (uint32_t)g.in[1], t1, 0, 1});
+                    A.push_back({BCE_AND, (uint32_t)g.in[0], (uint32_t)g.in[1], t2, 1, 0});
+                    B.push_back({BCE_OR, t1, t2, (uint32_t)g.out, 0, 0});
+                } else if (!me) {
+                    continue;
+                } else if (g.op == GateEnum::AND || g.op == GateEnum::OR) {
+                    A.push_back({(uint32_t)(g.op == GateEnum::AND ? BCE_AND : BCE_OR), (uint32_t)g.in[0], (uint32_t)g.in[1], (uint32_t)g.out, 0, 0});
+                } else if (g.op == GateEnum::NOT) {
+                    A.push_back({BCE_OP_NOT, (uint32_t)g.in[0], (uint32_t)g.in[0], (uint32_t)g.out, 0, 0});
+                }
+            }
+            const uint32_t K = hi - lo;
+            if (!A.empty()) {
+                // descriptors address instance `lo`; the strided call replicates them K times
+                for (auto& d : A) { d.in0 += lo * stride_; d.in1 += lo * stride_; d.out += lo * stride_; }
+                ck(bce_eval_gates_strided(cc, (uint32_t)A.size(), A.data(), K, stride_), "Clock(stage A)");
+                ++stats_.sublaunches;
+            }
+            if (!B.empty()) {
+                for (auto& d : B) { d.in0 += lo * stride_; d.in1 += lo * stride_; d.out += lo * stride_; }
+                ck(bce_eval_gates_strided(cc, (uint32_t)B.size(), B.data(), K, stride_), "Clock(stage B)");
+                ++stats_.sublaunches;
+            }
+        } else {
+            // reference shape: one Gate::Evaluate per gate (src/circuit.cpp:698-710)
+            GateEvalParams p = gep;
+            p.plaintext_flag = false;  // plaintext was done above for every instance
+            p.verify_flag = false;
+            for (unsigned i = lo; i < hi; ++i) {
+                uint32_t x = 0;
+                for (size_t k = 0; k < L.gates.size(); ++k) {
+                    const GateRec& g = allGates[L.gates[k]];
+                    uint32_t xi = (g.op == GateEnum::XOR) ? x++ : 0;
+                    if (!mine(k) || g.op == GateEnum::OUTPUT) continue;
+                    Gate ge;
+                    ge.name = g.name; ge.op = g.op;
+                    for (int q = 0; q < g.nin; ++q) { ge.encin.push_back(i * stride_ + g.in[q]); ge.ready.push_back(true); }
+                    ge.encout.assign(1, i * stride_ + g.out);
+                    ge.tmp = {i * stride_ + tmp0 + 2 * xi, i * stride_ + tmp0 + 2 * xi + 1};
+                    ge.Evaluate(p);
+                }
+            }
+        }
+        if (verify_flag) {
+            // decrypt every output of the level, compare with the plaintext pass, repair mismatches
+            std::vector<uint32_t> slots;
+            std::vector<uint8_t> expect;
+            std::vector<const char*> names;
+            for (unsigned i = lo; i < hi; ++i)
+                for (size_t k = 0; k < L.gates.size(); ++k) {
+                    const GateRec& g = allGates[L.gates[k]];
+                    if (!mine(k)) continue;
+                    int w = g.op == GateEnum::OUTPUT ? g.in[0] : g.out;
+                    slots.push_back(i * stride_ + w);
+                    expect.push_back(plain_[i][w]);
+                    names.push_back(op_name(g.op));
+                }
+            std::vector<uint8_t> got(slots.size());
+            if (!slots.empty()) ck(bce_decrypt_bits(cc, slots.data(), (uint32_t)slots.size(), got.data()), "Clock(verify)");
+            for (size_t k = 0; k < slots.size(); ++k) {
+                if (got[k] == expect[k]) continue;
+                std::cerr << "Bad " << names[k] << " fixing" << std::endl;
+                ++stats_.verify_fixes;
+                if (std::strcmp(names[k], "OUTPUT") != 0)
+                    ck(bce_encrypt_bits(cc, &expect[k], &slots[k], 1, (1ull << 40) + enc_counter_++, BCE_FRESH), "Clock(fix)");
+            }
+        }
+    }
+    exchangeLevel(level);
+
+    // retire: counters (once per evaluation, src/circuit.cpp:722-749) and OUTPUT gates (:796-807)
+    std::vector<uint32_t> oslots;
+    std::vector<std::pair<unsigned, int>> obits;
+    for (size_t k = 0; k < L.gates.size(); ++k) {
+        const GateRec& g = allGates[L.gates[k]];
+        switch (g.op) {
+            case GateEnum::OUTPUT: ++n_output_gates; break;
+            case GateEnum::NOT: ++n_not_gates; break;
+            case GateEnum::AND: ++n_and_gates; break;
+            case GateEnum::OR: ++n_or_gates; break;
+            case GateEnum::XOR: ++n_xor_gates; break;
+            default: break;
+        }
+        if (g.op != GateEnum::OUTPUT) continue;
+        if (!encrypted_flag && !plaintext_flag) std::cerr << "Error either encrypted or plaintext flag must be set" << std::endl;
+        for (unsigned i = lo; i < hi; ++i) {
+            if (encrypted_flag) { oslots.push_back(i * stride_ + g.in[0]); obits.push_back({i, g.out_bit}); }
+            else circuitOut[i][g.out_bit] = plain_[i][g.in[0]];
+        }
+    }
+    if (!oslots.empty()) {
+        std::vector<uint8_t> res(oslots.size());
+        ck(bce_decrypt_bits(cc, oslots.data(), (uint32_t)oslots.size(), res.data()), "Clock(Decrypt)");
+        for (size_t k = 0; k < oslots.size(); ++k) circuitOut[obits[k].first][obits[k].second] = res[k];
+    }
+}
+
+Outputs Circuit::Clock() {
+    if (done) throw std::logic_error("done ckt clocked! should reset");  // the reference exits (src/circuit.cpp:538-541)
+    auto t_total = Clock_t::now();
+    double management = 0, execution = 0;
+    uint64_t boots0 = 0;
+    if (encrypted_flag) {
+        requireEngine("Clock");
+        ck(bce_pool_reserve(cc, instances_ * stride_), "Clock(pool)");
+        bce_timing t;
+        ck(bce_timing_get(cc, &t), "Clock");
+        boots0 = t.bootstraps;
+    }
+    size_t done_gates = 0;
+    for (size_t l = 0; l < levels_.size() && inputs_set_; ++l) {
+        auto t0 = Clock_t::now();
+        managerRound(l);
+        management += ms_since(t0);
+        t0 = Clock_t::now();
+        executeRound(l);
+        execution += ms_since(t0);
+        done_gates += levels_[l].gates.size();
+        ++stats_.levels;
+        if (!quiet_) std::cout << "\rProcessing: " << done_gates << " of " << allGates.size() << std::flush;
+    }
+    if (encrypted_flag) {
+        auto t0 = Clock_t::now();
+        bce_timing t;
+        ck(bce_timing_get(cc, &t), "Clock");  // synchronizes
+        stats_.bootstraps = t.bootstraps - boots0;
+        execution += ms_since(t0);
+    }
+    gatherOutputs();
+    if (done_gates == allGates.size()) done = true;
+    stats_.total_ms = ms_since(t_total);
+    stats_.management_ms = management;
+    stats_.execution_ms = execution;
+    if (!quiet_) {
+        std::cout << std::endl << "### Total time " << (unsigned)std::max(1.0, stats_.total_ms) << " msec" << std::endl;
+        std::cout << std::endl << "efficiency " << float(std::max(1.0, execution)) / float(std::max(1.0, stats_.total_ms)) * 100.0 << "%" << std::endl;
+    }
+    return getOutputs(0);
+}
+
+Outputs Circuit::getOutputs(unsigned instance) const {
+    Outputs o(1);
+    if (instance < circuitOut.size()) o[0].assign(circuitOut[instance].begin(), circuitOut[instance].end());
+    return o;
+}
+
+void Circuit::getCounts(uint32_t out[6]) const {
+    out[0] = n_input_gates; out[1] = n_output_gates; out[2] = n_not_gates;
+    out[3] = n_and_gates; out[4] = n_or_gates; out[5] = n_xor_gates;
+}
+
+bce_circuit_info Circuit::info() const {
+    bce_circuit_info I{};
+    I.n_gates = (uint32_t)allGates.size();
+    I.n_input_gates = (uint32_t)inputGates.size();
+    I.n_wires = (uint32_t)wire_names_.size();
+    I.n_inputs = n_buses_;
+    I.n_input_bits[0] = n_in_bits_[0];
+    I.n_input_bits[1] = n_in_bits_[1];
+    I.n_output_bits = n_output_bits.empty() ? 0 : n_output_bits[0];
+    I.n_levels = (uint32_t)levels_.size();
+    for (const auto& L : levels_) {
+        uint32_t a = 0, b = 0;
+        for (int gi : L.gates) {
+            GateEnum op = allGates[gi].op;
+            if (op == GateEnum::AND || op == GateEnum::OR) ++a;
+            if (op == GateEnum::XOR) { a += 2; ++b; }
+        }
+        if (a) ++I.n_sublaunches;
+        if (b) ++I.n_sublaunches;
+        I.max_frontier = std::max(I.max_frontier, std::max(a, b));
+        I.n_bootstraps += a + b;
+    }
+    return I;
+}
+
+void Circuit::dumpNetList() const {
+    std::cout << "Netlist " << std::endl;
+    NetList nl;
+    for (size_t w = 0; w < wire_names_.size(); ++w) {
+        NameList& f = nl[wire_names_[w]];
+        for (uint32_t e = fan_off_[w]; e < fan_off_[w + 1]; ++e) f.push_back(allGates[fan_gate_[e]].name);
+    }
+    for (const auto& it : nl) {
+        std::cout << it.first;
+        for (const auto& g : it.second) std::cout << " " << g;
+        std::cout << std::endl;
+    }
+}
+
+void Circuit::dumpGates() const {
+    std::cout << "Inputlist " << std::endl;
+    for (const auto& l : inputGates) std::cout << l.name << std::endl;
+    std::cout << "Alllist " << std::endl;
+    for (const auto& g : allGates) std::cout << g.name << std::endl;
+}
+
+void Circuit::dumpGateCount() const {
+    std::cout << "Number of input gates " << n_input_gates << std::endl;
+    std::cout << "Number of output gates " << n_output_gates << std::endl;
+    std::cout << "Number of not gates " << n_not_gates << std::endl;
+    std::cout << "Number of and gates " << n_and_gates << std::endl;
+    std::cout << "Number of or gates " << n_or_gates << std::endl;
+    std::cout << "Number of xor gates " << n_xor_gates << std::endl;
+}
+
+}  // namespace bce

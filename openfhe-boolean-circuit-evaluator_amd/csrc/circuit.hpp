@@ -1,0 +1,194 @@
+// circuit.hpp -- host circuit runtime: Wire, Gate, GateEvalParams, Circuit.
+//
+// Keeps the reference's driver API (src/wire.h:48-69, src/gate.h:50-80, src/circuit.h:54-114)
+// with two deliberate differences:
+//   * `CipherText` is a slot of the engine's device-resident LWE pool (include/bce_gpu.h)
+//     instead of lbcrypto::LWECiphertext (src/wire.h:46);
+//   * the DAG is indexed (gate ids, CSR fan-out, ready counters) and levelised once, and the
+//     executor hands each ready frontier to bce_eval_gates() instead of one OpenMP task per
+//     gate (src/circuit.cpp:698-710).  The O(G^2) netlist build (src/circuit.cpp:323-354) and
+//     the O(wires x waiting gates) manager scan (src/circuit.cpp:593-677) are not inherited.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/bce_circuit.h"
+#include "../../include/bce_gpu.h"
+
+namespace bce {
+
+using NameList = std::vector<std::string>;
+using CipherText = uint32_t;  // pool slot (reference: lbcrypto::LWECiphertext)
+constexpr CipherText kNoCipherText = 0xFFFFFFFFu;
+
+// src/wire.h:48-69
+class Wire {
+public:
+    void setName(const std::string& n) { name = n; }
+    std::string getName() const { return name; }
+    void setValue(bool b) { value = b; }
+    bool getValue() const { return value; }
+    void setFanoutGates(const NameList& f) { fanoutGates = f; }
+    NameList getFanoutGates() const { return fanoutGates; }
+    unsigned int getNumberFanoutGates() const { return (unsigned int)fanoutGates.size(); }
+    void setCipherText(CipherText c) { ct = c; }
+    CipherText getCipherText() const { return ct; }
+    // erases the first match, or reports an error (src/wire.cpp:54-65)
+    void updateFanoutGates(const std::string& gateToRemove);
+
+private:
+    std::string name;
+    NameList fanoutGates;
+    bool value = false;
+    CipherText ct = kNoCipherText;
+};
+
+using ReadyList = std::vector<bool>;
+using CipherTextList = std::vector<CipherText>;
+using BitList = std::vector<unsigned int>;
+
+enum class GateEnum { INPUT, OUTPUT, NOT, AND, OR, XOR, DFF, LUT3, LUT4 };  // src/gate.h:50
+
+// src/gate.h:52-63; `cc` is the engine handle and plays BinFHEContext + secret key
+class GateEvalParams {
+public:
+    bool plaintext_flag = false;
+    bool encrypted_flag = false;
+    bool verify_flag = false;
+    bce_ctx* cc = nullptr;
+    uint64_t* enc_counter = nullptr;  // PRNG stream index for verify-mode re-encryptions
+    unsigned int* fixes = nullptr;    // counts "Bad <OP> fixing" events
+};
+
+// src/gate.h:65-80
+class Gate {
+public:
+    void Reset() {}
+    // plaintext logic and/or encrypted logic for this one gate (src/gate.cpp:49-229).
+    // Encrypted: encout[0] must hold the destination slot; XOR also needs tmp[0], tmp[1].
+    void Evaluate(const GateEvalParams&);
+    std::string name;
+    GateEnum op = GateEnum::INPUT;
+    NameList inWireNames;
+    ReadyList ready;
+    NameList outWireNames;
+    CipherTextList encin;
+    BitList plainin;
+    CipherTextList encout;
+    BitList plainout;
+    CipherTextList tmp;  // scratch slots for the XOR expansion
+};
+
+using Inputs = std::vector<std::vector<unsigned int>>;
+using Outputs = std::vector<std::vector<unsigned int>>;
+using NetList = std::map<std::string, NameList>;
+
+class Circuit {
+public:
+    // Circuit(set, method), src/circuit.cpp:45-98: creates the engine on device 0 and generates
+    // keys.  Accepts only TOY / STD128_OPT and AP / GINX like the reference; throws otherwise.
+    Circuit(int paramset, int method);
+    // shares an existing engine (keys already generated); nullptr = plaintext-only circuit
+    explicit Circuit(bce_ctx* engine);
+    ~Circuit();
+
+    bool ReadFile(const std::string& cktName);                 // src/circuit.cpp:102-366
+    bool ReadBristol(const std::string& path, bool new_flag);  // direct netlist -> DAG
+    void Reset();                                              // src/circuit.cpp:368-419
+    void SetInput(const Inputs& input, bool verbose = false);  // src/circuit.cpp:455-530
+    void SetInput(unsigned instance, const Inputs& input, bool verbose = false);
+    void setPlaintext(bool b) { plaintext_flag = gep.plaintext_flag = b; }
+    bool getPlaintext() const { return plaintext_flag; }
+    void setEncrypted(bool b) { encrypted_flag = gep.encrypted_flag = b; }
+    bool getEncrypted() const { return encrypted_flag; }
+    void setVerify(bool b);                                    // src/circuit.cpp:833-840
+    bool getVerify() const { return verify_flag; }
+    Outputs Clock();                                           // src/circuit.cpp:532-573
+    void dumpNetList() const;
+    void dumpGates() const;
+    void dumpGateCount() const;
+
+    // ---- extensions --------------------------------------------------------------
+    void setInstances(unsigned k);            // K lock-step input sets (before SetInput)
+    unsigned getInstances() const { return instances_; }
+    void setBatched(bool b) { batched_ = b; }
+    void setEncryptMode(int mode) { encrypt_mode_ = mode; }
+    void setQuiet(bool q) { quiet_ = q; }
+    Outputs getOutputs(unsigned instance) const;
+    void getCounts(uint32_t out[6]) const;
+    const bce_circuit_stats& stats() const { return stats_; }
+    bce_circuit_info info() const;
+    void setExchange(uint32_t rank, uint32_t world, int shard_mode, bce_allgather_fn fn, void* user, void* host_send,
+                     void* host_recv, void* dev_send, void* dev_recv, uint64_t capacity);
+    uint64_t exchangeCapacity(uint32_t world, int shard_mode, bool encrypted) const;
+    bce_ctx* engine() const { return cc; }
+
+private:
+    struct GateRec {
+        GateEnum op;
+        int nin;
+        int in[2];
+        int out;      // wire id, -1 for OUTPUT
+        int out_bit;  // OUTPUT only
+        std::string name;
+    };
+    struct LoadRec { unsigned bus, bit; int wire; std::string name; };
+    struct Level {
+        std::vector<int> gates;  // file order
+        uint32_t n_xor = 0;
+    };
+
+    bce_ctx* cc = nullptr;
+    bool owns_engine_ = false;
+    bool plaintext_flag = false, encrypted_flag = false, verify_flag = false;
+    bool done = false, inputs_set_ = false, quiet_ = false, batched_ = true;
+    int encrypt_mode_ = BCE_FRESH;
+    GateEvalParams gep;
+
+    std::vector<LoadRec> inputGates;  // LOADs
+    std::vector<GateRec> allGates;    // everything else, file order
+    std::vector<std::string> wire_names_;
+    std::map<uint32_t, int> wire_of_reg_;
+    std::vector<uint32_t> fan_off_, fan_gate_;  // CSR wire -> consumer gates
+    std::vector<Level> levels_;
+    std::vector<int> gate_level_;
+    uint32_t max_level_xor_ = 0, stride_ = 0;
+    unsigned n_outputs = 1;
+    std::vector<unsigned> n_output_bits;
+    unsigned n_in_bits_[2] = {0, 0}, n_buses_ = 0;
+
+    unsigned instances_ = 1;
+    std::vector<std::vector<uint8_t>> plain_;       // [instance][wire]
+    std::vector<std::vector<uint8_t>> circuitOut;   // [instance][bit]
+    uint64_t enc_counter_ = 0, epoch_ = 0;
+    unsigned n_input_gates = 0, n_output_gates = 0, n_and_gates = 0, n_or_gates = 0, n_xor_gates = 0, n_not_gates = 0;
+    bce_circuit_stats stats_{};
+    std::string err_;
+
+    // multi-rank
+    uint32_t rank_ = 0, world_ = 1;
+    int shard_mode_ = 0;
+    bce_allgather_fn xfn_ = nullptr;
+    void* xuser_ = nullptr;
+    void *host_send_ = nullptr, *host_recv_ = nullptr, *dev_send_ = nullptr, *dev_recv_ = nullptr;
+    uint64_t xcap_ = 0;
+    std::vector<std::vector<uint8_t>> owner_;                 // [level][k] owner rank of levels_[level].gates[k]
+    std::vector<std::vector<std::vector<int>>> xwires_;       // [level][rank] -> wires that rank must publish
+
+    int addWire(uint32_t reg);
+    int wireOf(uint32_t reg, const char* what, unsigned lineNo) const;
+    void finalizeNetlist();
+    void buildShardPlan();
+    void instanceRange(unsigned& lo, unsigned& hi) const;
+    void managerRound(size_t level);
+    void executeRound(size_t level);
+    void exchangeLevel(size_t level);
+    void gatherOutputs();
+    void requireEngine(const char* what) const;
+    void ck(int rc, const char* what) const;
+    friend struct ::bce_circuit;
+};
+
+}  // namespace bce

@@ -16,6 +16,7 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/bce_circuit.h"
 #include "../../include/bce_gpu.h"
 #include "host_math.hpp"
 #include "kernels.hpp"
@@ -726,6 +727,32 @@ int bce_debug_eval_stages(bce_ctx* c, uint32_t n_desc, const bce_gate_desc* desc
     for (u32 i = 0; i < n_desc; ++i)
         if (!(descs[i].op <= BCE_XNOR_FAST || descs[i].op == BCE_OP_REFRESH)) return c->fail(BCE_ERR_ARG, "staged outputs need bootstrapped ops only");
     return eval_impl(c, n_desc, descs, 1, 0, acc, lweN, ks);
+}
+
+static int pool_pack(bce_ctx* c, const uint32_t* slots, uint32_t count, void* dev, int to_pool) {
+    if (!c || !slots || !dev) return BCE_ERR_ARG;
+    if (count == 0) return BCE_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<bce_gate_desc> d(count);
+    for (u32 i = 0; i < count; ++i) {
+        if (slots[i] >= c->pool_slots) return c->fail(BCE_ERR_POOL, "slot %u outside the pool", slots[i]);
+        d[i] = bce_gate_desc{BCE_OP_COPY, slots[i], slots[i], slots[i], 0, 0};
+    }
+    bce_gate_desc* dd = nullptr;
+    int slot = 0;
+    int rc = stage_descs(c, d.data(), count, &dd, &slot);
+    if (rc) return rc;
+    HIP_TRY(c, launch_pool_pack(c->P, dd, count, (u32*)dev, to_pool, c->stream));
+    hipEventRecord(c->ring_ev[slot], c->stream);
+    c->ring_busy[slot] = true;
+    return BCE_OK;
+}
+
+int bce_pool_gather(bce_ctx* c, const uint32_t* slots, uint32_t count, void* dev_dst) {
+    return pool_pack(c, slots, count, dev_dst, 0);
+}
+int bce_pool_scatter(bce_ctx* c, const uint32_t* slots, uint32_t count, const void* dev_src) {
+    return pool_pack(c, slots, count, const_cast<void*>(dev_src), 1);
 }
 
 int bce_debug_ntt(bce_ctx* c, uint64_t* polys, uint32_t count, int inverse) {

@@ -481,6 +481,21 @@ hipError_t launch_lwe_unary(const DevParams& P, const bce_gate_desc* d, u32 n_de
     return hipGetLastError();
 }
 
+// pool rows <-> dense buffer [count][n+1] (multi-rank exchange); slot = descs[i].in0
+__global__ void k_pool_pack(DevParams P, const bce_gate_desc* __restrict__ descs, u32* __restrict__ buf, int to_pool) {
+    u32* row = P.pool + (size_t)descs[blockIdx.x].in0 * P.pool_stride;
+    u32* b = buf + (size_t)blockIdx.x * (P.n + 1);
+    for (u32 i = threadIdx.x; i <= P.n; i += blockDim.x) {
+        if (to_pool) row[i] = b[i]; else b[i] = row[i];
+    }
+}
+
+hipError_t launch_pool_pack(const DevParams& P, const bce_gate_desc* d, u32 count, u32* buf, int to_pool, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pool_pack, dim3(count), dim3(256), 0, s, P, d, buf, to_pool);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------
 // batched NTT over global memory (key import / key generation / debug), one wave per poly
 // ---------------------------------------------------------------------------------------

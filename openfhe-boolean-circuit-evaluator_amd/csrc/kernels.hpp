@@ -51,6 +51,10 @@ hipError_t launch_tail(const DevParams& P, const bce_gate_desc* d_descs, u32 n_d
 hipError_t launch_lwe_unary(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances,
                             u32 slot_stride, hipStream_t s);
 
+// dense buffer [count][n+1] u32 <-> pool rows named by d_descs[i].in0
+hipError_t launch_pool_pack(const DevParams& P, const bce_gate_desc* d_descs, u32 count, u32* buf, int to_pool,
+                            hipStream_t s);
+
 // in-place negacyclic NTT of `count` polys, u32 [count][N] in global memory
 hipError_t launch_ntt_batch(const DevParams& P, u32* polys, u32 count, int inverse, hipStream_t s);
 

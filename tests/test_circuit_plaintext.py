@@ -1,0 +1,180 @@
+"""Host circuit runtime + Bristol front end against the reference harnesses' functional KATs
+(plaintext mode needs no GPU).  Sources of every vector: tests/kat.py."""
+import os
+
+import pytest
+
+import kat
+from kat import CIRCUITS
+
+
+def _run(c, inputs):
+    c.Reset()
+    c.setPlaintext(True)
+    c.setEncrypted(False)
+    c.setVerify(False)
+    c.SetInput(inputs)
+    return c.Clock()[0]
+
+
+@pytest.fixture(scope="module")
+def asm_dir(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("asm"))
+
+
+def _assembled(bce, asm_dir, name, new_flag=False):
+    out = os.path.join(asm_dir, name.replace(".txt", "") + "_FHE.out")
+    if not os.path.exists(out):
+        bce.assemble_bristol(os.path.join(CIRCUITS, name), out, new_flag=new_flag)
+    c = bce.Circuit()
+    c.ReadFile(out)
+    return c
+
+
+def test_adder_2bit_all_inputs_and_counters(bce):
+    c = bce.Circuit()
+    c.ReadFile(os.path.join(CIRCUITS, "adder_2bit.out"))
+    info = c.info()
+    assert (info["n_input_gates"], info["n_output_bits"], info["n_bootstraps"], info["n_levels"]) == (4, 3, 13, 4)
+    for a in range(4):
+        for b in range(4):
+            o = _run(c, [[a & 1, a >> 1], [b & 1, b >> 1]])
+            assert o[0] + 2 * o[1] + 4 * o[2] == a + b
+    assert c.counts() == {"input": 4, "output": 3, "not": 0, "and": 3, "or": 1, "xor": 3}
+    for t in range(10):                                   # the harness's srand(test_ix) draws
+        ins, want = kat.adder_case(t, 2)
+        assert _run(c, ins) == want
+
+
+def test_flags_follow_the_reference(bce):
+    c = bce.Circuit()
+    c.ReadFile(os.path.join(CIRCUITS, "adder_2bit.out"))
+    c.setVerify(True)                                     # forces plaintext and encrypted on
+    assert (c.getPlaintext(), c.getEncrypted(), c.getVerify()) == (True, True, True)
+    c.Reset()                                             # clears all three flags
+    assert (c.getPlaintext(), c.getEncrypted(), c.getVerify()) == (False, False, False)
+    c.setPlaintext(True)
+    c.SetInput([[1, 1], [1, 0]])
+    c.Clock()
+    with pytest.raises(bce.BceError):                     # "done ckt clocked! should reset"
+        c.Clock()
+
+
+def test_parity_with_cascade(bce):
+    c = bce.Circuit()
+    c.ReadFile(os.path.join(CIRCUITS, "parity.out"))
+    for t in range(10):
+        ins, want = kat.parity_case(t)
+        assert _run(c, ins) == want
+        # second run feeds the even bit back as bit 8 (src/test_parity.cpp:293-297)
+        ins2 = [ins[0][:8] + [want[0]]]
+        odd2 = sum(ins2[0]) & 1
+        assert _run(c, ins2) == [1 - odd2, odd2]
+
+
+@pytest.mark.parametrize("name,nbits", [("adder_32bit.txt", 32), ("adder_64bit.txt", 64)])
+def test_adders(bce, asm_dir, name, nbits):
+    c = _assembled(bce, asm_dir, name)
+    for t in range(10):
+        ins, want = kat.adder_case(t, nbits)
+        assert _run(c, ins) == want
+    if nbits == 64:
+        i = c.info()
+        assert (i["n_gates"] - i["n_output_bits"], i["n_bootstraps"], i["n_sublaunches"], i["max_frontier"]) == (759, 610, 291, 74)
+        assert c.counts()["xor"] == 115 and c.counts()["and"] == 265 and c.counts()["not"] == 379
+
+
+@pytest.mark.parametrize("name", ["comparator_32bit_signed_lt.txt", "comparator_32bit_signed_lteq.txt",
+                                  "comparator_32bit_unsigned_lt.txt", "comparator_32bit_unsigned_lteq.txt"])
+def test_comparators(bce, asm_dir, name):
+    c = _assembled(bce, asm_dir, name)
+    assert c.info()["n_bootstraps"] == 150
+    for t in range(10):
+        ins, want = kat.comparator_case(t, name)
+        assert _run(c, ins) == want
+
+
+def test_multiplier(bce, asm_dir):
+    c = _assembled(bce, asm_dir, "mult_32x32.txt")
+    assert c.info()["n_bootstraps"] == 9133
+    for t in range(5):
+        ins, want = kat.multiplier_case(t)
+        assert _run(c, ins) == want
+
+
+def test_md5(bce, asm_dir):
+    c = _assembled(bce, asm_dir, "md5.txt")
+    assert c.info()["n_bootstraps"] == 71534
+    for inhex, outhex in kat.hash_vectors("md5-test.txt"):
+        ins, want = kat.md5_case(inhex, outhex)
+        assert _run(c, [ins[0], []]) == want
+
+
+def test_sha256_new_format_direct(bce):
+    c = bce.Circuit()
+    c.ReadBristol(os.path.join(CIRCUITS, "sha256_new.txt"), new_flag=True)
+    i = c.info()
+    assert (i["n_gates"] - 256, i["n_bootstraps"], i["n_input_bits"]) == (135073, 354505, [512, 256])
+    vecs = kat.hash_vectors("sha-256-test.txt")
+    assert len(vecs) == 4
+    for inhex, outhex in vecs:
+        ins, want = kat.sha256_new_case(inhex, outhex)
+        assert _run(c, ins) == want
+
+
+@pytest.mark.parametrize("v", kat.AES_VECTORS, ids=lambda v: "%s-%d" % (v["circuit"], v["case"]))
+def test_aes(bce, asm_dir, v):
+    c = _assembled(bce, asm_dir, v["circuit"] + ".txt")
+    ins, want = kat.aes_case(v)
+    assert _run(c, ins) == want
+    if v["circuit"] == "AES-expanded":
+        i = c.info()
+        assert (i["n_gates"] - 128, i["n_bootstraps"], i["n_sublaunches"], i["max_frontier"], i["n_levels"]) == \
+            (27692, 66415, 496, 376, 249)
+
+
+def test_assembler_text_format(bce, asm_dir):
+    """App. A of SURVEY.md: header, LOAD/gate/STORE lines, statistics trailer (src/assemble.cpp)"""
+    out = os.path.join(asm_dir, "adder_32bit_fmt.out")
+    bce.assemble_bristol(os.path.join(CIRCUITS, "adder_32bit.txt"), out)
+    lines = open(out).read().splitlines()
+    assert lines[:4] == ["# Max depth 10000", "# number input1 bits 32", "# number input2 bits 32",
+                         "# number output1 bits 33"]
+    assert lines[4] == "R0 = LOAD(In1,0)" and lines[36] == "R32 = LOAD(In2,0)"
+    body = [l for l in lines if not l.startswith("#")]
+    assert sum("XOR(" in l and l.endswith("  !depth = 1") for l in body) == 61
+    assert sum(" = AND(" in l and l.endswith(") !depth = 1") for l in body) == 127
+    assert sum(" = NOT(" in l and l.endswith(") !depth = 0") for l in body) == 187
+    stores = [l for l in body if l.startswith("Out")]
+    assert len(stores) == 33 and stores[0].startswith("Out0 = STORE(R") and stores[0].endswith(" ! depth = 0")
+    assert lines[-6:] == ["# Assembler statistics", "# max depth supported: 10000", "# max depth required: 0",
+                          "# max tower jump: 0", "# %d registers used" % (64 + 375), "# 0 BOOT operations required"]
+    # the text path and the direct netlist path build the same DAG
+    a, b = bce.Circuit(), bce.Circuit()
+    a.ReadFile(out)
+    b.ReadBristol(os.path.join(CIRCUITS, "adder_32bit.txt"))
+    assert a.info() == b.info()
+
+
+def test_reader_rejects_malformed_programs(bce, tmp_path):
+    p = tmp_path / "bad.out"
+    p.write_text("R0 = LOAD(In1,0)\nR1 = AND(R0, R7)\n")
+    c = bce.Circuit()
+    with pytest.raises(bce.BceError) as e:
+        c.ReadFile(str(p))
+    assert "AND parse error line 2" in str(e.value)
+    with pytest.raises(bce.BceError):
+        c.ReadFile(str(tmp_path / "missing.out"))
+
+
+def test_k_instances_in_lock_step(bce, asm_dir):
+    c = _assembled(bce, asm_dir, "adder_32bit.txt")
+    c.setInstances(4)
+    c.Reset()
+    c.setPlaintext(True)
+    cases = [kat.adder_case(t, 32) for t in range(4)]
+    for k, (ins, _) in enumerate(cases):
+        c.SetInput(ins, instance=k)
+    c.Clock()
+    for k, (_, want) in enumerate(cases):
+        assert c.Outputs(k)[0] == want

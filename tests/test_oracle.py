@@ -1,0 +1,156 @@
+"""The CPU oracle against what pins it: number-theory values, algebraic identities, gate truth
+tables and the committed golden vectors.  Ciphertext-level parity with OpenFHE itself is
+UNPINNED (OpenFHE is absent; the reference stores no ciphertext)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from kat import GOLDEN
+
+
+def test_prime_search_and_roots(orc):
+    L = orc.lib()
+    # FirstPrime / minimal primitive 2N-th roots as computed in SURVEY.md App. D.1
+    assert L.bo_first_prime(27, 2048) == 134246401 and L.bo_min_primitive_root(134246401, 2048) == 455622
+    assert L.bo_first_prime(27, 1024) == 134224897 and L.bo_min_primitive_root(134224897, 1024) == 341565
+    assert L.bo_first_prime(37, 4096) == 137439006721 and L.bo_min_primitive_root(137439006721, 4096) == 13167220
+    # GenerateBinFHEContext uses PreviousPrime(FirstPrime(bits, 2N), 2N): the 27-bit NTT prime 2^27 - 2^11 + 1
+    assert L.bo_previous_prime(134246401, 2048) == 134215681 == (1 << 27) - (1 << 11) + 1
+    assert L.bo_previous_prime(134224897, 1024) == 134215681
+
+
+@pytest.mark.parametrize("ps,exp", [
+    ("TOY", dict(n=64, N=512, q=512, Q=134215681, qKS=134215681, baseKS=25, dKS=6, baseG=512, dG=3, baseR=23, dR=2)),
+    ("STD128_OPT", dict(n=502, N=1024, q=1024, Q=134215681, qKS=16384, baseKS=128, dKS=2, baseG=128, dG=4, baseR=32, dR=2)),
+    ("STD128", dict(n=512, N=1024, q=1024, Q=134215681, qKS=16384, baseKS=128, dKS=2, baseG=128, dG=4)),
+    ("STD192", dict(n=1024, N=2048, q=1024, Q=137438822401, qKS=1 << 19, baseKS=28, dKS=4, baseG=1 << 13, dG=3, baseR=32, dR=2)),
+])
+def test_parameter_sets(orc, ps, exp):
+    o = orc.Oracle(getattr(orc, ps), orc.GINX)
+    for k, v in exp.items():
+        assert o.params[k] == v, (ps, k)
+
+
+def _negacyclic_schoolbook(a, b, Q):
+    N = len(a)
+    out = [0] * N
+    for i in range(N):
+        if a[i] == 0:
+            continue
+        for j in range(N):
+            k = i + j
+            v = a[i] * b[j]
+            if k >= N:
+                out[k - N] = (out[k - N] - v) % Q
+            else:
+                out[k] = (out[k] + v) % Q
+    return out
+
+
+def test_ntt_is_negacyclic_convolution(orc):
+    o = orc.Oracle(orc.TOY, orc.GINX)
+    Q, N = o.params["Q"], o.N
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, Q, N, dtype=np.uint64)
+    b = np.zeros(N, dtype=np.uint64)
+    idx = rng.choice(N, 12, replace=False)
+    b[idx] = rng.integers(0, Q, 12, dtype=np.uint64)
+    fa, fb = o.ntt_forward(a), o.ntt_forward(b)
+    prod = np.array([(int(x) * int(y)) % Q for x, y in zip(fa, fb)], dtype=np.uint64)
+    got = o.ntt_inverse(prod)
+    want = _negacyclic_schoolbook([int(x) for x in b], [int(x) for x in a], Q)
+    assert [int(x) for x in got] == want
+    assert np.array_equal(o.ntt_inverse(fa), a)
+
+
+def _truth(gate, a, b):
+    return [a | b, a & b, 1 - (a | b), 1 - (a & b), a ^ b, 1 - (a ^ b)][gate]
+
+
+@pytest.mark.parametrize("method", ["GINX", "AP"])
+def test_truth_tables_toy(orc, method):
+    o = orc.Oracle(orc.TOY, getattr(orc, method))
+    o.keygen(2024)
+    q = o.params["q"]
+    idx = 0
+    worst = 0
+    for gate in range(6):
+        for a in (0, 1):
+            for b in (0, 1):
+                ca, cb = o.encrypt(a, idx), o.encrypt(b, idx + 1)
+                idx += 2
+                r = o.eval_bingate(gate, ca, cb)
+                want = _truth(gate, a, b)
+                assert o.decrypt(r) == want
+                assert o.decrypt(o.eval_not(r)) == 1 - want
+                worst = max(worst, abs(o.noise(r, want)))
+                # staged entry points compose to EvalBinGate
+                acc = o.blind_rotate(gate, o.gate_prep(gate, ca, cb))
+                assert np.array_equal(o.modswitch_final(o.keyswitch(o.extract_modswitch(acc))), r)
+    assert worst < q // 8, "bootstrapped noise must stay below the decryption threshold q/8"
+    c1 = o.encrypt(1, 999)
+    assert o.decrypt(o.bootstrap(c1)) == 1 and o.decrypt(o.bootstrap(o.eval_not(c1))) == 0
+
+
+def test_xor_as_the_reference_builds_it(orc):
+    """XOR = OR(AND(a, !b), AND(!a, b)), src/gate.cpp:198-202"""
+    o = orc.Oracle(orc.TOY, orc.GINX)
+    o.keygen(5)
+    for a in (0, 1):
+        for b in (0, 1):
+            ca, cb = o.encrypt(a, 10 + 2 * a + b), o.encrypt(b, 20 + 2 * a + b)
+            t1 = o.eval_bingate(orc.AND, ca, o.eval_not(cb))
+            t2 = o.eval_bingate(orc.AND, o.eval_not(ca), cb)
+            assert o.decrypt(o.eval_bingate(orc.OR, t1, t2)) == a ^ b
+
+
+def test_batched_eval_matches_single(orc):
+    o = orc.Oracle(orc.TOY, orc.GINX)
+    o.keygen(11)
+    W = o.n + 1
+    pool = np.zeros((8, W), dtype=np.uint64)
+    pool[0], pool[1] = o.encrypt(1, 0), o.encrypt(0, 1)
+    descs = [(orc.AND, 0, 1, 2, 0, 1), (orc.AND, 0, 1, 3, 1, 0), (orc.OP_NOT, 0, 0, 4, 0, 0),
+             (orc.OP_REFRESH, 1, 1, 5, 0, 0), (orc.OP_COPY, 0, 0, 6, 0, 0)]
+    nb = o.eval_gates(pool, descs, nthreads=2)
+    assert nb == 3
+    assert np.array_equal(pool[2], o.eval_bingate(orc.AND, pool[0], o.eval_not(pool[1])))
+    assert np.array_equal(pool[3], o.eval_bingate(orc.AND, o.eval_not(pool[0]), pool[1]))
+    assert np.array_equal(pool[4], o.eval_not(pool[0]))
+    assert np.array_equal(pool[5], o.bootstrap(pool[1]))
+    assert np.array_equal(pool[6], pool[0])
+
+
+def test_committed_golden_vectors(orc):
+    g = json.load(open(os.path.join(GOLDEN, "oracle_golden_toy.json")))
+    o = orc.Oracle(orc.TOY, orc.GINX)
+    o.keygen(g["seed"])
+    assert o.params == g["params"]
+    assert o.sk().tolist() == g["sk"]
+    ca, cb = o.encrypt(1, 0), o.encrypt(0, 1)
+    assert ca.tolist() == g["ct_a_bit1_idx0"] and cb.tolist() == g["ct_b_bit0_idx1"]
+    for name, want in g["gates"].items():
+        assert o.eval_bingate(getattr(orc, name), ca, cb).tolist() == want, name
+    assert o.eval_not(ca).tolist() == g["not_a"]
+    assert o.bootstrap(ca).tolist() == g["bootstrap_a"]
+
+
+def test_custom_context_with_the_survey_modulus(orc):
+    """SURVEY.md App. D.1 quotes Q = FirstPrime(27, 2N) = 134,246,401 (4 digits of 2^9 for TOY);
+    the algorithm is modulus-agnostic, so that variant must work too."""
+    o = orc.Oracle(method=orc.GINX, custom=(64, 512, 512, 134224897, 0, 25, 1 << 9, 23))
+    assert o.params["dG"] == 4 and o.params["psi"] == 341565
+    o.keygen(3)
+    ca, cb = o.encrypt(1, 0), o.encrypt(1, 1)
+    assert o.decrypt(o.eval_bingate(orc.AND, ca, cb)) == 1
+    assert o.decrypt(o.eval_bingate(orc.NAND, ca, cb)) == 0
+
+
+def test_std128_single_gate(orc):
+    o = orc.Oracle(orc.STD128_OPT, orc.GINX)
+    o.keygen(1)
+    ca, cb = o.encrypt(1, 0), o.encrypt(0, 1)
+    r = o.eval_bingate(orc.OR, ca, cb)
+    assert o.decrypt(r) == 1 and abs(o.noise(r, 1)) < 128
