@@ -68,6 +68,9 @@ int bce_circuit_get_info(const bce_circuit*, bce_circuit_info* out);
 
 /* Circuit::Reset / setPlaintext / setEncrypted / setVerify, src/circuit.cpp:368-419,819-842 */
 int bce_circuit_reset(bce_circuit*);
+/* extension: allow another Clock() on the same inputs (mode flags and the input ciphertexts
+ * resident in the device pool are kept; counters and the done flag are cleared) */
+int bce_circuit_rearm(bce_circuit*);
 int bce_circuit_set_plaintext(bce_circuit*, int on);
 int bce_circuit_set_encrypted(bce_circuit*, int on);
 int bce_circuit_set_verify(bce_circuit*, int on);

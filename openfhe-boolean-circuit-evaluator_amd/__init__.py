@@ -284,7 +284,7 @@ ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_int)
 
 CIRCUIT_SYMBOLS = [
     "bce_circuit_create", "bce_circuit_destroy", "bce_circuit_last_error", "bce_circuit_read_file",
-    "bce_circuit_read_bristol", "bce_circuit_get_info", "bce_circuit_reset", "bce_circuit_set_plaintext",
+    "bce_circuit_read_bristol", "bce_circuit_get_info", "bce_circuit_reset", "bce_circuit_rearm", "bce_circuit_set_plaintext",
     "bce_circuit_set_encrypted", "bce_circuit_set_verify", "bce_circuit_get_flags", "bce_circuit_set_batched",
     "bce_circuit_set_encrypt_mode", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
     "bce_circuit_get_output", "bce_circuit_get_counts", "bce_circuit_get_stats", "bce_circuit_dump",
@@ -309,7 +309,7 @@ def _bind_circuit():
     L.bce_circuit_read_file.argtypes = [vp, C.c_char_p]
     L.bce_circuit_read_bristol.argtypes = [vp, C.c_char_p, i32]
     L.bce_circuit_get_info.argtypes = [vp, C.POINTER(CircuitInfo)]
-    for name in ("reset", "clock"):
+    for name in ("reset", "rearm", "clock"):
         getattr(L, "bce_circuit_" + name).argtypes = [vp]
     for name in ("set_plaintext", "set_encrypted", "set_verify", "set_batched", "set_encrypt_mode", "dump"):
         getattr(L, "bce_circuit_" + name).argtypes = [vp, i32]
@@ -399,6 +399,9 @@ class Circuit:
 
     def Reset(self):
         self._ck(self._L.bce_circuit_reset(self.h))
+
+    def Rearm(self):
+        self._ck(self._L.bce_circuit_rearm(self.h))
 
     def setPlaintext(self, b):
         self._ck(self._L.bce_circuit_set_plaintext(self.h, int(b)))

@@ -348,6 +348,13 @@ void Circuit::Reset() {
     stats_ = bce_circuit_stats{};
 }
 
+void Circuit::Rearm() {
+    if (!inputs_set_) throw std::logic_error("Rearm: SetInput has not been called");
+    n_output_gates = n_and_gates = n_or_gates = n_xor_gates = n_not_gates = 0;
+    done = false;
+    stats_ = bce_circuit_stats{};
+}
+
 void Circuit::setVerify(bool b) {
     verify_flag = gep.verify_flag = b;
     if (b) { setPlaintext(true); setEncrypted(true); }

@@ -116,6 +116,9 @@ public:
     void setBatched(bool b) { batched_ = b; }
     void setEncryptMode(int mode) { encrypt_mode_ = mode; }
     void setQuiet(bool q) { quiet_ = q; }
+    // re-arm for another Clock() on the SAME inputs: keeps mode flags and the input ciphertexts
+    // already resident in the device pool (registers are SSA, inputs are never overwritten)
+    void Rearm();
     Outputs getOutputs(unsigned instance) const;
     void getCounts(uint32_t out[6]) const;
     const bce_circuit_stats& stats() const { return stats_; }

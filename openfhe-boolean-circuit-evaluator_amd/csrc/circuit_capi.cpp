@@ -61,6 +61,7 @@ int bce_circuit_get_info(const bce_circuit* h, bce_circuit_info* out) {
     return BCE_OK;
 }
 int bce_circuit_reset(bce_circuit* h) { return guarded(h, [&] { h->c.Reset(); }); }
+int bce_circuit_rearm(bce_circuit* h) { return guarded(h, [&] { h->c.Rearm(); }); }
 int bce_circuit_set_plaintext(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setPlaintext(on != 0); }); }
 int bce_circuit_set_encrypted(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setEncrypted(on != 0); }); }
 int bce_circuit_set_verify(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setVerify(on != 0); }); }

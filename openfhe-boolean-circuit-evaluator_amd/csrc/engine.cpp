@@ -586,15 +586,20 @@ int bce_lwe_write(bce_ctx* c, const uint32_t* slots, uint32_t count, const uint6
     if (!c || !slots || !cts) return BCE_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t W = c->n + 1;
-    std::vector<u32> row(W);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (u32 i = 0; i < count; ++i) {
-        if (slots[i] >= c->pool_slots) return c->fail(BCE_ERR_POOL, "slot %u outside the pool", slots[i]);
-        for (size_t k = 0; k < W; ++k) {
-            if (cts[i * W + k] >= c->q) return c->fail(BCE_ERR_ARG, "ciphertext word not reduced mod q");
-            row[k] = (u32)cts[i * W + k];
+    std::vector<u32> buf;
+    for (u32 i = 0; i < count;) {
+        u32 run = 1;  // coalesce runs of consecutive slots into one copy
+        while (i + run < count && slots[i + run] == slots[i] + run) ++run;
+        if ((u64)slots[i] + run > c->pool_slots) return c->fail(BCE_ERR_POOL, "slot %u outside the pool", slots[i] + run - 1);
+        buf.resize((size_t)run * W);
+        for (size_t k = 0; k < (size_t)run * W; ++k) {
+            const u64 v = cts[(size_t)i * W + k];
+            if (v >= c->q) return c->fail(BCE_ERR_ARG, "ciphertext word not reduced mod q");
+            buf[k] = (u32)v;
         }
-        HIP_TRY(c, hipMemcpy(c->d_pool + (size_t)slots[i] * c->P.pool_stride, row.data(), W * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_pool + (size_t)slots[i] * c->P.pool_stride, buf.data(), buf.size() * 4, hipMemcpyHostToDevice));
+        i += run;
     }
     return BCE_OK;
 }

@@ -1,0 +1,51 @@
+"""torch.distributed plumbing for multi-rank circuit evaluation (one process per GPU).
+
+The C++ circuit runtime decides WHAT crosses ranks (include/bce_circuit.h: set_exchange); this
+module only provides the allgather it calls back into: RCCL (backend "nccl") on device buffers,
+or gloo on host buffers for CPU-only tests.  Buffers are torch tensors whose data_ptr() is
+registered with the runtime.
+"""
+import torch
+import torch.distributed as dist
+
+
+class Exchange:
+    def __init__(self, circuit, shard_mode, encrypted, device=None, group=None):
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.group = group
+        self.device = device
+        cap = circuit.exchange_capacity(self.world, shard_mode, encrypted)
+        cap = (max(cap, 64) + 63) // 64 * 64
+        self.cap = cap
+        self.host_send = torch.zeros(cap, dtype=torch.uint8)
+        self.host_recv = torch.zeros(cap * self.world, dtype=torch.uint8)
+        self.dev_send = self.dev_recv = None
+        if device is not None:
+            self.dev_send = torch.zeros(cap, dtype=torch.uint8, device=device)
+            self.dev_recv = torch.zeros(cap * self.world, dtype=torch.uint8, device=device)
+        self.calls = 0
+        circuit.set_exchange(self.rank, self.world, shard_mode, self._allgather,
+                             self.host_send.data_ptr(), self.host_recv.data_ptr(),
+                             self.dev_send.data_ptr() if device is not None else None,
+                             self.dev_recv.data_ptr() if device is not None else None, cap)
+
+    def _allgather(self, nbytes, on_device):
+        try:
+            self.calls += 1
+            if on_device:
+                # engine stream was synchronized by the runtime before this call
+                dist.all_gather_into_tensor(self.dev_recv[: nbytes * self.world], self.dev_send[:nbytes], group=self.group)
+                torch.cuda.synchronize(self.device)
+            elif self.device is not None and dist.get_backend(self.group) == "nccl":
+                # host payload (plaintext bits / final outputs) staged through the GPU for RCCL
+                self.dev_send[:nbytes].copy_(self.host_send[:nbytes])
+                dist.all_gather_into_tensor(self.dev_recv[: nbytes * self.world], self.dev_send[:nbytes], group=self.group)
+                self.host_recv[: nbytes * self.world].copy_(self.dev_recv[: nbytes * self.world])
+                torch.cuda.synchronize(self.device)
+            else:
+                dist.all_gather_into_tensor(self.host_recv[: nbytes * self.world], self.host_send[:nbytes], group=self.group)
+            return 0
+        except Exception as e:  # never raise through the C callback
+            print("exchange failed:", repr(e), flush=True)
+            return 1

@@ -1,0 +1,156 @@
+"""Encrypted circuit evaluation on the GPU through the Circuit driver: the reference's own
+functional known-answer tests (verify OFF, unlike the reference harness which repairs errors),
+batched frontier path == per-gate Gate::Evaluate path == CPU oracle, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import kat
+from kat import CIRCUITS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def toy_cc(bce):
+    c = bce.BinFHEContext(bce.TOY, bce.GINX)
+    c.KeyGen(0x0FE5EED)
+    return c
+
+
+@pytest.fixture(scope="module")
+def std_cc(bce):
+    c = bce.BinFHEContext(bce.STD128_OPT, bce.GINX)
+    c.KeyGen(0x0FE5EED)
+    return c
+
+
+def _enc_run(c, inputs, verify=False):
+    c.Reset()
+    c.setPlaintext(False)
+    c.setEncrypted(True)
+    if verify:
+        c.setVerify(True)
+    c.SetInput(inputs)
+    return c.Clock()[0]
+
+
+def test_adder_2bit_toy_encrypted_all_inputs(bce, toy_cc):
+    """BASELINE config 1: adder_2bit, TOY, GINX"""
+    c = bce.Circuit(toy_cc)
+    c.ReadFile(os.path.join(CIRCUITS, "adder_2bit.out"))
+    for a in range(4):
+        for b in range(4):
+            o = _enc_run(c, [[a & 1, a >> 1], [b & 1, b >> 1]])
+            assert o[0] + 2 * o[1] + 4 * o[2] == a + b
+    st = c.stats()
+    assert st["bootstraps"] == 13 and st["sublaunches"] == 5 and st["verify_fixes"] == 0
+    assert c.counts() == {"input": 4, "output": 3, "not": 0, "and": 3, "or": 1, "xor": 3}
+
+
+def test_batched_equals_per_gate_equals_oracle(bce, orc, toy_cc):
+    """same keys, same input ciphertexts: frontier batching must not change a single bit"""
+    o = orc.Oracle(orc.TOY, orc.GINX)
+    o.keygen(0x0FE5EED)
+    s, _ = toy_cc.export_sk()
+    assert np.array_equal(s, o.sk())
+    c = bce.Circuit(toy_cc)
+    c.ReadFile(os.path.join(CIRCUITS, "adder_2bit.out"))
+    ins = [[1, 0], [1, 1]]
+    outs = {}
+    c.Reset()
+    c.setEncrypted(True)
+    c.SetInput(ins)
+    for batched in (True, False):
+        c.setBatched(batched)
+        if not batched:
+            c.Rearm()                      # same input ciphertexts, second evaluation
+        c.Clock()
+        # registers R4 (XOR), R8 (XOR of XOR), R10 (OR): slots == wire ids in file order
+        outs[batched] = toy_cc.lwe_read(np.arange(0, 11, dtype=np.uint32))
+    assert np.array_equal(outs[True], outs[False])
+    # oracle replay of the netlist on the same input ciphertexts
+    R = {k: outs[True][k] for k in range(4)}
+    def xor(a, b):
+        return o.eval_bingate(orc.OR, o.eval_bingate(orc.AND, a, o.eval_not(b)), o.eval_bingate(orc.AND, o.eval_not(a), b))
+    R[4] = xor(R[0], R[2]); R[5] = o.eval_bingate(orc.AND, R[0], R[2])
+    R[6] = xor(R[1], R[3]); R[7] = o.eval_bingate(orc.AND, R[1], R[3])
+    R[8] = xor(R[5], R[6]); R[9] = o.eval_bingate(orc.AND, R[5], R[6])
+    R[10] = o.eval_bingate(orc.OR, R[9], R[7])
+    for k in range(4, 11):
+        assert np.array_equal(outs[True][k], R[k]), "register R%d differs from the oracle" % k
+
+
+def test_parity_toy_with_verify_mode(bce, toy_cc):
+    c = bce.Circuit(toy_cc)
+    c.ReadFile(os.path.join(CIRCUITS, "parity.out"))
+    for t in range(3):
+        ins, want = kat.parity_case(t)
+        assert _enc_run(c, ins, verify=True) == want
+        assert c.stats()["verify_fixes"] == 0
+
+
+def test_bootstrapped_input_mode(bce, toy_cc):
+    """OpenFHE v1.0.x Encrypt() default: one Bootstrap per input bit"""
+    c = bce.Circuit(toy_cc)
+    c.ReadFile(os.path.join(CIRCUITS, "adder_2bit.out"))
+    c.setEncryptMode(bce.BOOTSTRAPPED)
+    o = _enc_run(c, [[1, 1], [1, 0]])
+    assert o[0] + 2 * o[1] + 4 * o[2] == 3 + 1
+
+
+def test_adder_64bit_std128(bce, std_cc, tmp_path):
+    """BASELINE config 2: old_bristol adder_64bit, STD128_OPT GINX"""
+    out = str(tmp_path / "adder_64bit_FHE.out")
+    bce.assemble_bristol(os.path.join(CIRCUITS, "adder_64bit.txt"), out)
+    c = bce.Circuit(std_cc)
+    c.ReadFile(out)
+    for t in range(2):
+        ins, want = kat.adder_case(t, 64)
+        assert _enc_run(c, ins) == want
+    assert c.stats()["bootstraps"] == 610
+
+
+def test_adder_64bit_k_instances(bce, std_cc):
+    c = bce.Circuit(std_cc)
+    c.ReadBristol(os.path.join(CIRCUITS, "adder_64bit.txt"))
+    K = 8
+    c.setInstances(K)
+    c.Reset()
+    c.setEncrypted(True)
+    cases = [kat.adder_case(t, 64) for t in range(K)]
+    for k, (ins, _) in enumerate(cases):
+        c.SetInput(ins, instance=k)
+    c.Clock()
+    for k, (_, want) in enumerate(cases):
+        assert c.Outputs(k)[0] == want
+    assert c.stats()["bootstraps"] == 610 * K
+
+
+def test_comparator_and_multiplier_std128(bce, std_cc):
+    c = bce.Circuit(std_cc)
+    c.ReadBristol(os.path.join(CIRCUITS, "comparator_32bit_signed_lteq.txt"))
+    for t in range(2):
+        ins, want = kat.comparator_case(t, "comparator_32bit_signed_lteq.txt")
+        assert _enc_run(c, ins) == want
+    m = bce.Circuit(std_cc)
+    m.ReadBristol(os.path.join(CIRCUITS, "mult_32x32.txt"))
+    ins, want = kat.multiplier_case(1)
+    assert _enc_run(m, ins) == want
+
+
+def test_aes_expanded_std128_full_circuit(bce, std_cc):
+    """BASELINE config 3 (the headline workload): AES-expanded, both reference vectors in lock-step"""
+    c = bce.Circuit(std_cc)
+    c.ReadBristol(os.path.join(CIRCUITS, "AES-expanded.txt"))
+    vecs = [v for v in kat.AES_VECTORS if v["circuit"] == "AES-expanded"]
+    c.setInstances(len(vecs))
+    c.Reset()
+    c.setEncrypted(True)
+    for k, v in enumerate(vecs):
+        c.SetInput(kat.aes_case(v)[0], instance=k)
+    c.Clock()
+    for k, v in enumerate(vecs):
+        assert c.Outputs(k)[0] == kat.aes_case(v)[1]
+    assert c.stats()["bootstraps"] == 66415 * len(vecs)
