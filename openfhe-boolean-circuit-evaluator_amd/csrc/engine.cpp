@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -58,7 +59,7 @@ struct bce_ctx {
     hipStream_t stream = nullptr;
     DevParams P{};
     // device tables / keys
-    uint2 *d_twf = nullptr, *d_twi = nullptr;
+    uint2* d_twf = nullptr;
     u32* d_bsk = nullptr;
     void* d_ksk = nullptr;
     u64 bsk_polys = 0;
@@ -136,21 +137,18 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { g_create_error = "hipStreamCreate failed"; return BCE_ERR_HIP; }
 
     // twiddle tables, OpenFHE ordering: tw[brv(i)] = psi^i
-    std::vector<uint2> twf(N), twi(N);
-    u64 ipsi = pow_mod(c->psi, Q - 2, Q), p = 1, ip = 1;
+    std::vector<uint2> twf(N);
+    u64 p = 1;
     for (u32 i = 0; i < N; ++i) {
         u32 r = bit_reverse(i, (int)c->logN);
         twf[r] = make_uint2((u32)p, (u32)(((u128)p << 32) / Q));
-        twi[r] = make_uint2((u32)ip, (u32)(((u128)ip << 32) / Q));
         p = mul_mod(p, c->psi, Q);
-        ip = mul_mod(ip, ipsi, Q);
     }
-    if (hipMalloc(&c->d_twf, sizeof(uint2) * N) != hipSuccess || hipMalloc(&c->d_twi, sizeof(uint2) * N) != hipSuccess) {
+    if (hipMalloc(&c->d_twf, sizeof(uint2) * N) != hipSuccess) {
         g_create_error = "hipMalloc(twiddles) failed";
         return BCE_ERR_HIP;
     }
     hipMemcpy(c->d_twf, twf.data(), sizeof(uint2) * N, hipMemcpyHostToDevice);
-    hipMemcpy(c->d_twi, twi.data(), sizeof(uint2) * N, hipMemcpyHostToDevice);
     for (int i = 0; i < bce_ctx::kRing; ++i) hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming);
 
     DevParams& P = c->P;
@@ -167,7 +165,23 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     u64 ninv = pow_mod(N, Q - 2, Q);
     P.Ninv = (u32)ninv;
     P.Ninv_s = (u32)(((u128)ninv << 32) / Q);
-    P.tw_f = c->d_twf; P.tw_i = c->d_twi;
+    P.mu32 = (u32)((((u64)1) << 32) / Q);
+    P.lazy = ((u64)(2 * c->logN + 1) * Q < (((u64)1) << 32)) ? 1 : 0;
+    {
+        const char* occ = std::getenv("BCE_OCCUPANCY");  // development knob: 2 or 3 workgroups per CU
+        P.occupancy_target = (occ && occ[0] == '2') ? 2 : 3;
+        const size_t lds = (2 * (size_t)N + (2 + 2 * c->dG) * ((size_t)N + (N >> 6) * 4) + ((n + 1 + 3) & ~3u)) * 4;
+        if (3 * lds > 160 * 1024) P.occupancy_target = 2;
+    }
+    {
+        u64 I = pow_mod(c->psi, N / 2, Q), v = 1;
+        for (int k = 0; k < 4; ++k) {
+            P.I4[k] = (u32)v;
+            P.I4s[k] = (u32)(((u128)v << 32) / Q);
+            v = mul_mod(v, I, Q);
+        }
+    }
+    P.tw_f = c->d_twf;
     P.pool_stride = n + 1;
     *out = c.release();
     return BCE_OK;
@@ -381,7 +395,7 @@ void bce_ctx_destroy(bce_ctx* c) {
         if (c->h_descs[i]) hipHostFree(c->h_descs[i]);
         if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
     }
-    hipFree(c->d_twf); hipFree(c->d_twi); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc);
+    hipFree(c->d_twf); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }

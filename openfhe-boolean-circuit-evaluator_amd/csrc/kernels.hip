@@ -104,8 +104,10 @@ __device__ __forceinline__ void store_pass(u32* poly, u32 lane, const u32 (&x)[C
     }
 }
 
-// Cooley-Tukey stage on coefficient-index bit B (distance 2^B), twiddle tw[m + (j >> (B+1))]
-template <int LOGN, int LO, int B>
+// Cooley-Tukey stage on coefficient-index bit B (distance 2^B), twiddle tw[m + (j >> (B+1))].
+// LAZY: no per-stage correction at all -- every stage adds at most 2Q, so values stay below
+// (2*LOGN+1)*Q < 2^32 (host checks); otherwise Harvey's [0,4Q) form with one correction per stage.
+template <int LOGN, int LO, int B, bool LAZY>
 __device__ __forceinline__ void fwd_stage(u32 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q) {
     constexpr int LE = Cfg<LOGN>::LE, E = Cfg<LOGN>::E;
     constexpr int rb = B - LO;
@@ -116,14 +118,16 @@ __device__ __forceinline__ void fwd_stage(u32 (&x)[Cfg<LOGN>::E], u32 lane, cons
     for (int r = 0; r < E; ++r) {
         if (r & (1 << rb)) continue;
         uint2 w = tw[m + (hi | (u32)(r >> (rb + 1)))];
-        u32 X = csub(x[r], Q2);
+        u32 X = LAZY ? x[r] : csub(x[r], Q2);
         u32 T = mul_shoup_lazy(x[r | (1 << rb)], w, Q);
         x[r] = X + T;
         x[r | (1 << rb)] = X + Q2 - T;
     }
 }
 
-// Gentleman-Sande stage on bit B; values stay in [0, 2Q)
+// Gentleman-Sande stage on bit B; values stay in [0, 2Q).  Inverse twiddles come from the
+// FORWARD table: psi^-k = -psi^(N-k), i.e. itw[m+i] = Q - tw[m + (m-1-i)], and the Shoup
+// companion of Q - w is the bitwise complement of w's (Q is prime, so w*2^32/Q is never integral).
 template <int LOGN, int LO, int B>
 __device__ __forceinline__ void inv_stage(u32 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q) {
     constexpr int LE = Cfg<LOGN>::LE, E = Cfg<LOGN>::E;
@@ -134,18 +138,19 @@ __device__ __forceinline__ void inv_stage(u32 (&x)[Cfg<LOGN>::E], u32 lane, cons
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         if (r & (1 << rb)) continue;
-        uint2 w = tw[m + (hi | (u32)(r >> (rb + 1)))];
+        const uint2 f = tw[(2 * m - 1) - (hi | (u32)(r >> (rb + 1)))];
+        const uint2 w = make_uint2(Q - f.x, ~f.y);
         u32 X = x[r], Y = x[r | (1 << rb)];
         x[r] = csub(X + Y, Q2);
         x[r | (1 << rb)] = mul_shoup_lazy(X + Q2 - Y, w, Q);
     }
 }
 
-template <int LOGN, int LO, int BHI, int BLO>
+template <int LOGN, int LO, int BHI, int BLO, bool LAZY>
 __device__ __forceinline__ void fwd_stages(u32 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q) {
     if constexpr (BHI >= BLO) {
-        fwd_stage<LOGN, LO, BHI>(x, lane, tw, Q);
-        fwd_stages<LOGN, LO, BHI - 1, BLO>(x, lane, tw, Q);
+        fwd_stage<LOGN, LO, BHI, LAZY>(x, lane, tw, Q);
+        fwd_stages<LOGN, LO, BHI - 1, BLO, LAZY>(x, lane, tw, Q);
     }
 }
 template <int LOGN, int LO, int BLO, int BHI>
@@ -157,25 +162,34 @@ __device__ __forceinline__ void inv_stages(u32 (&x)[Cfg<LOGN>::E], u32 lane, con
 }
 
 // Forward negacyclic NTT of one polynomial by one wave, in place in LDS.
-// Input: natural order, values < 4Q.  Output: bit-reversed order, values in [0, Q).
-template <int LOGN>
-__device__ __forceinline__ void ntt_forward_wave(u32* poly, const uint2* twf, u32 lane, u32 Q) {
+// Input: natural order, values < Q (LAZY) or < 4Q.  Output: bit-reversed order, values in [0, Q).
+// mu32 = floor(2^32 / Q) (LAZY only).
+template <int LOGN, bool LAZY>
+__device__ __forceinline__ void ntt_forward_wave(u32* poly, const uint2* twf, u32 lane, u32 Q, u32 mu32) {
     using C = Cfg<LOGN>;
     u32 x[C::E];
     load_pass<LOGN, 6>(poly, lane, x);
-    fwd_stages<LOGN, 6, LOGN - 1, 6>(x, lane, twf, Q);
+    fwd_stages<LOGN, 6, LOGN - 1, 6, LAZY>(x, lane, twf, Q);
     store_pass<LOGN, 6>(poly, lane, x);
     wave_sync();
     load_pass<LOGN, C::F2LO>(poly, lane, x);
-    fwd_stages<LOGN, C::F2LO, 5, C::F2LO>(x, lane, twf, Q);
+    fwd_stages<LOGN, C::F2LO, 5, C::F2LO, LAZY>(x, lane, twf, Q);
     if constexpr (C::F2LO > 0) {
         store_pass<LOGN, C::F2LO>(poly, lane, x);
         wave_sync();
         load_pass<LOGN, 0>(poly, lane, x);
-        fwd_stages<LOGN, 0, C::F2LO - 1, 0>(x, lane, twf, Q);
+        fwd_stages<LOGN, 0, C::F2LO - 1, 0, LAZY>(x, lane, twf, Q);
     }
 #pragma unroll
-    for (int r = 0; r < C::E; ++r) x[r] = csub(csub(x[r], 2 * Q), Q);
+    for (int r = 0; r < C::E; ++r) {
+        if constexpr (LAZY) {
+            // x < (2*LOGN+1)*Q < 2^32: quotient estimate off by at most 2
+            u32 v = x[r] - __umulhi(x[r], mu32) * Q;
+            x[r] = csub(csub(v, 2 * Q), Q);
+        } else {
+            x[r] = csub(csub(x[r], 2 * Q), Q);
+        }
+    }
     store_pass<LOGN, 0>(poly, lane, x);
     wave_sync();
 }
@@ -223,30 +237,29 @@ __device__ __forceinline__ u32 gate_const(u32 op, u32 q) {
 // ---------------------------------------------------------------------------------------
 // blind rotation (GINX / CGGI): one workgroup = one gate bootstrap, one wave per RGSW row
 // ---------------------------------------------------------------------------------------
-template <int LOGN>
-__global__ __launch_bounds__(512) void k_blind_rotate_ginx(DevParams P, const bce_gate_desc* __restrict__ descs,
-                                                           u32 n_desc, u32 slot_stride, u32* __restrict__ acc_out) {
+// OCC = workgroups the register budget is sized for per CU (2 or 3); LDS per workgroup is
+// 8 KiB twiddles + (2 + 2*DG) padded polynomials + ctprep = 52.5 KiB at N = 1024, DG = 4.
+template <int LOGN, int DG, bool LAZY, int OCC>
+__global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rotate_ginx(
+    DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc, u32 slot_stride, u32* __restrict__ acc_out) {
     using C = Cfg<LOGN>;
     constexpr int N = C::N, NP = C::NP, E = C::E;
+    constexpr u32 R = 2 * DG;
+    constexpr u32 T = 64 * R;
     extern __shared__ __align__(16) u32 smem[];
-    const u32 R = 2 * P.dG;
     uint2* twf = reinterpret_cast<uint2*>(smem);
-    uint2* twi = twf + N;
-    u32* acc = reinterpret_cast<u32*>(twi + N);  // [2][NP]  EVALUATION domain, [0,Q)
+    u32* acc = reinterpret_cast<u32*>(twf + N);  // [2][NP]  EVALUATION domain, [0,Q)
     u32* dct = acc + 2 * NP;                     // [R][NP]
     u32* av = dct + R * NP;                      // ctprep: a[0..n), b
 
-    const u32 tid = threadIdx.x, T = blockDim.x;
+    const u32 tid = threadIdx.x;
     const u32 lane = tid & 63, wave = tid >> 6;
     const u32 Q = P.Q, q = P.q, qm = q - 1, n = P.n;
 
     const bce_gate_desc g = descs[blockIdx.x % n_desc];
     const u32 soff = (blockIdx.x / n_desc) * slot_stride;
 
-    for (u32 i = tid; i < (u32)N; i += T) {
-        twf[i] = P.tw_f[i];
-        twi[i] = P.tw_i[i];
-    }
+    for (u32 i = tid; i < (u32)N; i += T) twf[i] = P.tw_f[i];
     {   // EvalBinGate LWE prep with folded EvalNOT: (-a, q/4 - b)
         const u32* in0 = P.pool + (size_t)(g.in0 + soff) * P.pool_stride;
         const u32* in1 = P.pool + (size_t)(g.in1 + soff) * P.pool_stride;
@@ -282,14 +295,12 @@ __global__ __launch_bounds__(512) void k_blind_rotate_ginx(DevParams P, const bc
         }
     }
     __syncthreads();
-    if (wave == 0) ntt_forward_wave<LOGN>(acc + NP, twf, lane, Q);
+    if (wave == 0) ntt_forward_wave<LOGN, LAZY>(acc + NP, twf, lane, Q, P.mu32);
     __syncthreads();
 
     const uint2 ninv = make_uint2(P.Ninv, P.Ninv_s);
-    const int gsh = 32 - (int)P.gBits;
-    const u32 Qh = Q >> 1;
-    const size_t rgsw = (size_t)R * 2 * N;  // words per RGSW ciphertext
-
+    constexpr u32 rgsw = R * 2 * N;  // words per RGSW ciphertext
+    // this thread's share of the MAC: component c, evaluation positions p0..p0+3 (loop when T < N/2)
     for (u32 i = 0; i < n; ++i) {
         const u32 ap = ((q - av[i]) & qm) * P.factor;  // exponent of the monomial, in [0, 2N)
         if (ap == 0) continue;                          // X^0 - 1 = 0: AddToAcc adds nothing
@@ -297,12 +308,15 @@ __global__ __launch_bounds__(512) void k_blind_rotate_ginx(DevParams P, const bc
         // (1) two waves: INTT of acc[c], SignedDigitDecompose -> dct[2l + c] (coefficient form)
         if (wave < 2) {
             u32 x[E];
-            ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, twi, lane, Q, ninv, x);
+            ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, twf, lane, Q, ninv, x);
+            const int gsh = 32 - (int)P.gBits;
+            const u32 Qh = Q >> 1;
 #pragma unroll
             for (int r = 0; r < E; ++r) {
                 int d = (x[r] < Qh) ? (int)x[r] : (int)x[r] - (int)Q;
                 const u32 pj = phys(((u32)r << 6) | lane);
-                for (u32 l = 0; l < P.dG; ++l) {
+#pragma unroll
+                for (u32 l = 0; l < (u32)DG; ++l) {
                     int rem = (int)((u32)d << gsh) >> gsh;  // signed digit in [-B/2, B/2)
                     d = (d - rem) >> P.gBits;
                     dct[(2 * l + wave) * NP + pj] = rem < 0 ? (u32)(rem + (int)Q) : (u32)rem;
@@ -311,33 +325,68 @@ __global__ __launch_bounds__(512) void k_blind_rotate_ginx(DevParams P, const bc
         }
         __syncthreads();
         // (2) one wave per decomposed polynomial: forward NTT in place
-        if (wave < R) ntt_forward_wave<LOGN>(dct + wave * NP, twf, lane, Q);
+        ntt_forward_wave<LOGN, LAZY>(dct + wave * NP, twf, lane, Q, P.mu32);
         __syncthreads();
         // (3) RGSW multiply-accumulate against ek+_i, ek-_i and the two monomials
         const u32* bk = P.bsk + (size_t)i * 2 * rgsw;
+        // I^a' and I^-a' for I = psi^(N/2): the 4 positions p0..p0+3 sit at evaluation points whose
+        // exponents differ by multiples of (N/2)*a' (brv(p0+e) = brv(p0) + {0,2,1,3}*N/4)
+        const u32 a4 = ap & 3u;
+        const uint2 Ia = make_uint2(P.I4[a4], P.I4s[a4]);
+        const uint2 Ina = make_uint2(P.I4[(4u - a4) & 3u], P.I4s[(4u - a4) & 3u]);
+        const bool odd = ap & 1u;
         for (u32 item = tid; item < 2u * (N / 4); item += T) {
             const u32 c = item / (N / 4), p0 = (item % (N / 4)) * 4;
             const u32 pp = phys(p0);
+            const u32* bp = bk + (size_t)c * N + p0;
+            // BSK rows: key+ (R loads) and the first half of key- in flight together; the second
+            // half of key- reuses key+'s registers once those are consumed (bounds VGPR pressure)
+            constexpr u32 H = R / 2;
+            uint4 kA[R], kB[H];
+#pragma unroll
+            for (u32 l = 0; l < R; ++l) kA[l] = *reinterpret_cast<const uint4*>(bp + (size_t)l * 2 * N);
+#pragma unroll
+            for (u32 l = 0; l < H; ++l) kB[l] = *reinterpret_cast<const uint4*>(bp + rgsw + (size_t)l * 2 * N);
+            __builtin_amdgcn_sched_barrier(0);
             u64 sp[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0};
+#pragma unroll
             for (u32 l = 0; l < R; ++l) {
                 const uint4 d = *reinterpret_cast<const uint4*>(dct + l * NP + pp);
-                const uint4 kp = *reinterpret_cast<const uint4*>(bk + ((size_t)l * 2 + c) * N + p0);
-                const uint4 kn = *reinterpret_cast<const uint4*>(bk + rgsw + ((size_t)l * 2 + c) * N + p0);
-                sp[0] += (u64)d.x * kp.x; sp[1] += (u64)d.y * kp.y; sp[2] += (u64)d.z * kp.z; sp[3] += (u64)d.w * kp.w;
-                sn[0] += (u64)d.x * kn.x; sn[1] += (u64)d.y * kn.y; sn[2] += (u64)d.z * kn.z; sn[3] += (u64)d.w * kn.w;
+                sp[0] += (u64)d.x * kA[l].x; sp[1] += (u64)d.y * kA[l].y; sp[2] += (u64)d.z * kA[l].z; sp[3] += (u64)d.w * kA[l].w;
             }
-            uint4 a4 = *reinterpret_cast<const uint4*>(acc + c * NP + pp);
-            u32 a[4] = {a4.x, a4.y, a4.z, a4.w};
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (u32 l = 0; l < H; ++l) kA[l] = *reinterpret_cast<const uint4*>(bp + rgsw + (size_t)(H + l) * 2 * N);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (u32 l = 0; l < H; ++l) {
+                const uint4 d = *reinterpret_cast<const uint4*>(dct + l * NP + pp);
+                sn[0] += (u64)d.x * kB[l].x; sn[1] += (u64)d.y * kB[l].y; sn[2] += (u64)d.z * kB[l].z; sn[3] += (u64)d.w * kB[l].w;
+            }
+#pragma unroll
+            for (u32 l = 0; l < H; ++l) {
+                const uint4 d = *reinterpret_cast<const uint4*>(dct + (H + l) * NP + pp);
+                sn[0] += (u64)d.x * kA[l].x; sn[1] += (u64)d.y * kA[l].y; sn[2] += (u64)d.z * kA[l].z; sn[3] += (u64)d.w * kA[l].w;
+            }
+            // monomials psi^(+-(2k+1)a') - 1 at the four positions
+            const u32 k0 = __brev(p0) >> (32 - LOGN);
+            const u32 ex = ((2 * k0 + 1) * ap) & (2 * N - 1);
+            u32 mp[4], mn[4];
+            mp[0] = psi_pow<LOGN>(twf, ex, Q);
+            mn[0] = psi_pow<LOGN>(twf, (2 * N - ex) & (2 * N - 1), Q);
+            mp[2] = csub(mul_shoup_lazy(mp[0], Ia, Q), Q);
+            mn[2] = csub(mul_shoup_lazy(mn[0], Ina, Q), Q);
+            mp[1] = odd ? Q - mp[0] : mp[0];
+            mn[1] = odd ? Q - mn[0] : mn[0];
+            mp[3] = odd ? Q - mp[2] : mp[2];
+            mn[3] = odd ? Q - mn[2] : mn[2];
+            uint4 a4v = *reinterpret_cast<const uint4*>(acc + c * NP + pp);
+            u32 a[4] = {a4v.x, a4v.y, a4v.z, a4v.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                // evaluation point of position p is psi^(2*brv(p)+1); mono = psi^((2k+1)*a') - 1
-                const u32 k = __brev(p0 + e) >> (32 - LOGN);
-                const u32 ex = ((2 * k + 1) * ap) & (2 * N - 1);
-                const u32 mp = psi_pow<LOGN>(twf, ex, Q) - 1;
-                const u32 mn = psi_pow<LOGN>(twf, (2 * N - ex) & (2 * N - 1), Q) - 1;
                 const u32 rp = barrett_reduce(sp[e], Q, P.red_shift, P.red_mu);
                 const u32 rn = barrett_reduce(sn[e], Q, P.red_shift, P.red_mu);
-                a[e] = barrett_reduce((u64)rp * mp + (u64)rn * mn + a[e], Q, P.red_shift, P.red_mu);
+                a[e] = barrett_reduce((u64)rp * (mp[e] - 1) + (u64)rn * (mn[e] - 1) + a[e], Q, P.red_shift, P.red_mu);
             }
             *reinterpret_cast<uint4*>(acc + c * NP + pp) = make_uint4(a[0], a[1], a[2], a[3]);
         }
@@ -347,7 +396,7 @@ __global__ __launch_bounds__(512) void k_blind_rotate_ginx(DevParams P, const bc
     // accumulator back to COEFFICIENT form for the extraction kernel
     if (wave < 2) {
         u32 x[E];
-        ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, twi, lane, Q, ninv, x);
+        ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, twf, lane, Q, ninv, x);
         u32* out = acc_out + ((size_t)blockIdx.x * 2 + wave) * N;
 #pragma unroll
         for (int r = 0; r < E; ++r) out[((u32)r << 6) | lane] = x[r];
@@ -356,22 +405,41 @@ __global__ __launch_bounds__(512) void k_blind_rotate_ginx(DevParams P, const bc
 
 size_t blind_rotate_lds_bytes(const DevParams& P) {
     const size_t N = P.N, NP = N + (N >> 6) * 4, R = 2 * P.dG;
-    return (2 * N * 2 + (2 + R) * NP + ((P.n + 1 + 3) & ~3u)) * sizeof(u32);
+    return (2 * N + (2 + R) * NP + ((P.n + 1 + 3) & ~3u)) * sizeof(u32);
 }
+
+namespace {
+using BrKernel = void (*)(DevParams, const bce_gate_desc*, u32, u32, u32*);
+template <int LOGN, int DG>
+BrKernel pick_br(bool lazy, int occ) {
+    if (lazy) return occ >= 3 ? k_blind_rotate_ginx<LOGN, DG, true, 3> : k_blind_rotate_ginx<LOGN, DG, true, 2>;
+    return occ >= 3 ? k_blind_rotate_ginx<LOGN, DG, false, 3> : k_blind_rotate_ginx<LOGN, DG, false, 2>;
+}
+template <int LOGN>
+BrKernel pick_br_dg(u32 dG, bool lazy, int occ) {
+    switch (dG) {
+        case 2: return pick_br<LOGN, 2>(lazy, occ);
+        case 3: return pick_br<LOGN, 3>(lazy, occ);
+        case 4: return pick_br<LOGN, 4>(lazy, occ);
+        default: return nullptr;
+    }
+}
+}  // namespace
 
 hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
                                u32* acc_out, hipStream_t s) {
     const u32 R = 2 * P.dG;
-    const dim3 grid(n_desc * instances), block(64 * (R < 2 ? 2 : R));
+    const dim3 grid(n_desc * instances), block(64 * R);
     const size_t lds = blind_rotate_lds_bytes(P);
-    void (*kern)(DevParams, const bce_gate_desc*, u32, u32, u32*) = nullptr;
+    const int occ = P.occupancy_target;
+    BrKernel kern = nullptr;
     switch (P.logN) {
-        case 9: kern = k_blind_rotate_ginx<9>; break;
-        case 10: kern = k_blind_rotate_ginx<10>; break;
-        case 11: kern = k_blind_rotate_ginx<11>; break;
-        default: return hipErrorInvalidValue;
+        case 9: kern = pick_br_dg<9>(P.dG, P.lazy != 0, occ); break;
+        case 10: kern = pick_br_dg<10>(P.dG, P.lazy != 0, occ); break;
+        case 11: kern = (P.dG <= 3) ? pick_br_dg<11>(P.dG, P.lazy != 0, 2) : nullptr; break;
+        default: break;
     }
-    if (block.x > 512) return hipErrorInvalidValue;
+    if (!kern) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, block, lds, s, P, d, n_desc, slot_stride, acc_out);
@@ -507,8 +575,7 @@ __global__ __launch_bounds__(256) void k_ntt_batch(DevParams P, u32* __restrict_
     uint2* tw = reinterpret_cast<uint2*>(smem);
     u32* buf = reinterpret_cast<u32*>(tw + N);
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
-    const uint2* src = inverse ? P.tw_i : P.tw_f;
-    for (u32 i = tid; i < (u32)N; i += blockDim.x) tw[i] = src[i];
+    for (u32 i = tid; i < (u32)N; i += blockDim.x) tw[i] = P.tw_f[i];
     __syncthreads();
     u32* mine = buf + wave * NP;
     for (u32 p = blockIdx.x * W + wave; p < count; p += gridDim.x * W) {
@@ -519,7 +586,7 @@ __global__ __launch_bounds__(256) void k_ntt_batch(DevParams P, u32* __restrict_
         }
         wave_sync();
         if (!inverse) {
-            ntt_forward_wave<LOGN>(mine, tw, lane, P.Q);
+            ntt_forward_wave<LOGN, false>(mine, tw, lane, P.Q, 0);
             for (int r = 0; r < E; ++r) {
                 u32 j = ((u32)r << 6) | lane;
                 gp[j] = mine[phys(j)];

@@ -27,8 +27,12 @@ struct DevParams {
     u32 red_shift;    // Barrett for x < 2^(2*bitlen(Q)+3): x1 = x >> red_shift
     u32 red_mu;       // floor(2^(32+red_shift) / Q)
     u32 Ninv, Ninv_s; // N^-1 mod Q and its Shoup companion
-    const uint2* tw_f;  // [N] (psi^brv(i), shoup), index m+i as in the CT forward NTT
-    const uint2* tw_i;  // [N] inverse powers, GS order
+    u32 mu32;         // floor(2^32 / Q): final reduction of the lazy forward NTT
+    u32 lazy;         // 1 when (2*logN+1)*Q < 2^32: forward butterflies need no per-stage correction
+    u32 occupancy_target;  // workgroups per CU the blind-rotation kernel is compiled for (2 or 3)
+    u32 I4[4], I4s[4];     // powers of I = psi^(N/2) (primitive 4th root of unity) and Shoup companions
+    const uint2* tw_f;  // [N] (psi^brv(i), shoup), index m+i as in the CT forward NTT; the inverse
+                        // transform derives psi^-k = -psi^(N-k) from the same table
     const u32* bsk;     // EVALUATION domain, GINX [n][2][R][2][N]; AP [n][baseR][dR][R][2][N]
     const void* ksk;    // [N][baseKS][dKS][ksk_stride]
     u32* pool;          // [slots][pool_stride]
