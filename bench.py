@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=8, help="AES blocks evaluated in lock-step per GPU")
+    ap.add_argument("--instances", type=int, default=16, help="AES blocks evaluated in lock-step per GPU")
     ap.add_argument("--circuit", default="AES-expanded.txt")
     ap.add_argument("--paramset", default="STD128_OPT")
     ap.add_argument("--shard", choices=["instances", "gates"], default="instances")

@@ -166,7 +166,19 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     P.Ninv = (u32)ninv;
     P.Ninv_s = (u32)(((u128)ninv << 32) / Q);
     P.mu32 = (u32)((((u64)1) << 32) / Q);
-    P.lazy = ((u64)(2 * c->logN + 1) * Q < (((u64)1) << 32)) ? 1 : 0;
+    P.c32 = (u32)((((u64)1) << 32) % Q);
+    {
+        // lazy forward NTT: inputs < 2Q, every stage adds < 2Q -> outputs < B*Q with B = 2*logN+2.
+        // needs (1) B*Q < 2^32, (2) R*B*Q*Q < 2^64 for the 64-bit MAC sums, (3) the folded sum
+        // (x>>32)*c32 + 2^32 below the Barrett input bound 2^(32+red_shift)
+        const u128 B = 2 * c->logN + 2, R = 2 * c->dG;
+        const u128 sum = R * B * Q * Q;
+        const bool ok1 = B * Q < ((u128)1 << 32);
+        const bool ok2 = sum < ((u128)1 << 64);
+        const u128 folded = (sum >> 32) * P.c32 + ((u128)1 << 32);
+        const bool ok3 = folded < ((u128)1 << (32 + P.red_shift));
+        P.lazy = (ok1 && ok2 && ok3) ? 1 : 0;
+    }
     {
         const char* occ = std::getenv("BCE_OCCUPANCY");  // development knob: 2 or 3 workgroups per CU
         P.occupancy_target = (occ && occ[0] == '2') ? 2 : 3;

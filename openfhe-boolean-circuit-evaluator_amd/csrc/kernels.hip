@@ -44,6 +44,11 @@ __device__ __forceinline__ u32 barrett_reduce(u64 x, u32 Q, u32 shift, u32 mu) {
     return csub(r, Q);
 }
 
+// x < 2^64 with (x >> 32) * c32 + (x & 0xFFFFFFFF) < 2^(32+shift), c32 = 2^32 mod Q: fold, then reduce
+__device__ __forceinline__ u32 barrett_fold(u64 x, u32 c32, u32 Q, u32 shift, u32 mu) {
+    return barrett_reduce((u64)(u32)(x >> 32) * c32 + (u32)x, Q, shift, mu);
+}
+
 // ---------------------------------------------------------------------------------------
 // LDS polynomial layout and register passes
 // ---------------------------------------------------------------------------------------
@@ -162,9 +167,10 @@ __device__ __forceinline__ void inv_stages(u32 (&x)[Cfg<LOGN>::E], u32 lane, con
 }
 
 // Forward negacyclic NTT of one polynomial by one wave, in place in LDS.
-// Input: natural order, values < Q (LAZY) or < 4Q.  Output: bit-reversed order, values in [0, Q).
+// Input: natural order, values < 2Q (LAZY) or < 4Q.  Output: bit-reversed order, values in [0, Q)
+// (or merely < (2*LOGN+2)*Q when LAZY && !NORM).
 // mu32 = floor(2^32 / Q) (LAZY only).
-template <int LOGN, bool LAZY>
+template <int LOGN, bool LAZY, bool NORM = true>
 __device__ __forceinline__ void ntt_forward_wave(u32* poly, const uint2* twf, u32 lane, u32 Q, u32 mu32) {
     using C = Cfg<LOGN>;
     u32 x[C::E];
@@ -180,16 +186,18 @@ __device__ __forceinline__ void ntt_forward_wave(u32* poly, const uint2* twf, u3
         load_pass<LOGN, 0>(poly, lane, x);
         fwd_stages<LOGN, 0, C::F2LO - 1, 0, LAZY>(x, lane, twf, Q);
     }
+    if constexpr (NORM || !LAZY) {
 #pragma unroll
-    for (int r = 0; r < C::E; ++r) {
-        if constexpr (LAZY) {
-            // x < (2*LOGN+1)*Q < 2^32: quotient estimate off by at most 2
-            u32 v = x[r] - __umulhi(x[r], mu32) * Q;
-            x[r] = csub(csub(v, 2 * Q), Q);
-        } else {
-            x[r] = csub(csub(x[r], 2 * Q), Q);
+        for (int r = 0; r < C::E; ++r) {
+            if constexpr (LAZY) {
+                // x < (2*LOGN+2)*Q < 2^32: quotient estimate off by at most 2
+                u32 v = x[r] - __umulhi(x[r], mu32) * Q;
+                x[r] = csub(csub(v, 2 * Q), Q);
+            } else {
+                x[r] = csub(csub(x[r], 2 * Q), Q);
+            }
         }
-    }
+    }  // else: outputs stay below (2*LOGN+2)*Q; the RGSW MAC folds them (barrett_fold)
     store_pass<LOGN, 0>(poly, lane, x);
     wave_sync();
 }
@@ -319,13 +327,14 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
                 for (u32 l = 0; l < (u32)DG; ++l) {
                     int rem = (int)((u32)d << gsh) >> gsh;  // signed digit in [-B/2, B/2)
                     d = (d - rem) >> P.gBits;
-                    dct[(2 * l + wave) * NP + pj] = rem < 0 ? (u32)(rem + (int)Q) : (u32)rem;
+                    // LAZY: rem + Q (in (Q-B/2, Q+B/2)) is as good an input as rem mod Q for the lazy NTT
+                    dct[(2 * l + wave) * NP + pj] = LAZY ? (u32)(rem + (int)Q) : (rem < 0 ? (u32)(rem + (int)Q) : (u32)rem);
                 }
             }
         }
         __syncthreads();
         // (2) one wave per decomposed polynomial: forward NTT in place
-        ntt_forward_wave<LOGN, LAZY>(dct + wave * NP, twf, lane, Q, P.mu32);
+        ntt_forward_wave<LOGN, LAZY, false>(dct + wave * NP, twf, lane, Q, P.mu32);
         __syncthreads();
         // (3) RGSW multiply-accumulate against ek+_i, ek-_i and the two monomials
         const u32* bk = P.bsk + (size_t)i * 2 * rgsw;
@@ -384,8 +393,8 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
             u32 a[4] = {a4v.x, a4v.y, a4v.z, a4v.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const u32 rp = barrett_reduce(sp[e], Q, P.red_shift, P.red_mu);
-                const u32 rn = barrett_reduce(sn[e], Q, P.red_shift, P.red_mu);
+                const u32 rp = LAZY ? barrett_fold(sp[e], P.c32, Q, P.red_shift, P.red_mu) : barrett_reduce(sp[e], Q, P.red_shift, P.red_mu);
+                const u32 rn = LAZY ? barrett_fold(sn[e], P.c32, Q, P.red_shift, P.red_mu) : barrett_reduce(sn[e], Q, P.red_shift, P.red_mu);
                 a[e] = barrett_reduce((u64)rp * (mp[e] - 1) + (u64)rn * (mn[e] - 1) + a[e], Q, P.red_shift, P.red_mu);
             }
             *reinterpret_cast<uint4*>(acc + c * NP + pp) = make_uint4(a[0], a[1], a[2], a[3]);

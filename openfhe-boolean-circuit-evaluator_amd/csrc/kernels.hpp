@@ -28,7 +28,8 @@ struct DevParams {
     u32 red_mu;       // floor(2^(32+red_shift) / Q)
     u32 Ninv, Ninv_s; // N^-1 mod Q and its Shoup companion
     u32 mu32;         // floor(2^32 / Q): final reduction of the lazy forward NTT
-    u32 lazy;         // 1 when (2*logN+1)*Q < 2^32: forward butterflies need no per-stage correction
+    u32 lazy;         // 1 when the forward NTT can run without any correction (bounds in engine.cpp)
+    u32 c32;          // 2^32 mod Q (folds 64-bit MAC sums of un-normalised NTT outputs)
     u32 occupancy_target;  // workgroups per CU the blind-rotation kernel is compiled for (2 or 3)
     u32 I4[4], I4s[4];     // powers of I = psi^(N/2) (primitive 4th root of unity) and Shoup companions
     const uint2* tw_f;  // [N] (psi^brv(i), shoup), index m+i as in the CT forward NTT; the inverse
