@@ -113,7 +113,6 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     if (!is_prime_u64(Q) || (Q - 1) % (2ull * N)) { g_create_error = "Q must be a prime = 1 mod 2N"; return BCE_ERR_ARG; }
     if (Q >= (1ull << 28)) { g_create_error = "ring modulus Q >= 2^28 needs the 64-bit kernels (not built in this round)"; return BCE_ERR_UNSUPPORTED; }
     if (baseG & (baseG - 1)) { g_create_error = "gadget base must be a power of two"; return BCE_ERR_ARG; }
-    if (method == BCE_AP) { g_create_error = "AP (DM) blind rotation is not built in this round"; return BCE_ERR_UNSUPPORTED; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         g_create_error = "no HIP device visible: the engine has no CPU fallback";
@@ -129,7 +128,7 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     c->dKS = digit_count((double)c->qKS, (double)baseKS);
     c->dG = digit_count((double)Q, (double)baseG);
     c->dR = digit_count((double)q, (double)baseR);
-    if (2 * c->dG > 8) { g_create_error = "more than 8 RGSW rows per ciphertext is not supported"; return BCE_ERR_UNSUPPORTED; }
+    if (c->dG < 3 || c->dG > 4 || (N == 2048 && c->dG != 3)) { g_create_error = "gadget digit count must be 3 or 4 (3 for N = 2048)"; return BCE_ERR_UNSUPPORTED; }
     if (c->qKS > 0xFFFFFFFFull) { g_create_error = "qKS must fit 32 bits"; return BCE_ERR_UNSUPPORTED; }
     c->psi = min_primitive_root(Q, 2ull * N);
 
@@ -157,6 +156,7 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     P.ksk_stride = (n + 1 + 63) & ~63u;
     P.ksk_u16 = c->qKS <= 65536 ? 1 : 0;
     P.gBits = c->gBits; P.dG = c->dG; P.baseR = baseR; P.dR = c->dR;
+    P.method_ap = method == BCE_AP ? 1 : 0;
     P.factor = (u32)(2 * N / q);
     P.Q8p1 = (u32)(Q / 8 + 1);
     int bq = bit_length(Q);
@@ -473,12 +473,14 @@ int bce_keygen(bce_ctx* c, const uint8_t seed[32]) {
         if (rc) return rc;
     }
 
-    // Bootstrapping key (GINX): ek[i][0] = RGSW(s_i == 1), ek[i][1] = RGSW(s_i == -1).
+    // Bootstrapping key.  GINX: ek[i][0] = RGSW(s_i == 1), ek[i][1] = RGSW(s_i == -1)
+    // (rgsw-acc-cggi.cpp KeyGenAcc).  AP: ek[i][v][k] = RGSW(X^{s_i * v * baseR^k * 2N/q}), v >= 1
+    // (rgsw-acc-dm.cpp KeyGenAcc; the v = 0 slots stay zero and are never read).
     // Host draws (a, e) per row and adds the gadget; the device does the NTTs and a*z.
     {
         const u32 R = 2 * c->dG;
         const u64 rows = rgsw_rows_total(c);
-        std::vector<u32> bsk(rows * 2 * N), ta(rows * N);
+        std::vector<u32> bsk(rows * 2 * N, 0), ta(rows * N, 0);
         std::vector<u64> gpow(c->dG);
         { u64 v = 1; for (u32 i = 0; i < c->dG; ++i) { gpow[i] = v; v = mul_mod(v, c->baseG, Q); } }
         u32* bp = bsk.data();
@@ -486,11 +488,29 @@ int bce_keygen(bce_ctx* c, const uint8_t seed[32]) {
         const u64* gp = gpow.data();
         const int32_t* s = c->s.data();
         const uint8_t* sd = c->seed;
+        const bool ap = c->method == BCE_AP;
+        const u32 BR = c->baseR, DR = c->dR;
+        const int64_t qq = (int64_t)c->q;
         parallel_for(rows, [=, &gauss](size_t rowid) {
             const u32 r = (u32)(rowid % R);
-            const u64 ek = rowid / R;            // i*2 + key
-            const u32 i = (u32)(ek / 2), key = (u32)(ek % 2);
-            const bool one = key == 0 ? (s[i] == 1) : (s[i] == -1);
+            const u64 ek = rowid / R;
+            bool one;
+            u32 mm = 0;
+            bool negate = false;
+            if (!ap) {
+                const u32 i = (u32)(ek / 2), key = (u32)(ek % 2);   // ek = i*2 + key
+                one = key == 0 ? (s[i] == 1) : (s[i] == -1);
+            } else {
+                const u32 k = (u32)(ek % DR), v = (u32)((ek / DR) % BR), i = (u32)(ek / DR / BR);
+                if (v == 0) return;
+                int64_t pw = 1;
+                for (u32 t = 0; t < k; ++t) pw *= BR;
+                const int64_t m = (int64_t)s[i] * (int64_t)v * pw;
+                int64_t e = (((m % qq) + qq) % qq) * (int64_t)(2 * N / qq);
+                if (e >= (int64_t)N) { e -= N; negate = true; }
+                mm = (u32)e;
+                one = true;
+            }
             ChaChaStream st(sd, kDomBSK, rowid);
             u32* a = bp + (rowid * 2 + 0) * N;
             u32* b = bp + (rowid * 2 + 1) * N;
@@ -499,7 +519,8 @@ int bce_keygen(bce_ctx* c, const uint8_t seed[32]) {
             for (u32 k = 0; k < N; ++k) b[k] = (u32)lift_signed(gauss.draw(st), Q);
             if (one) {
                 u32* tgt = (r & 1) ? b : a;      // row 2j: column 0, row 2j+1: column 1
-                tgt[0] = (u32)((tgt[0] + gp[r >> 1]) % Q);
+                const u64 g = gp[r >> 1];
+                tgt[mm] = (u32)((tgt[mm] + (negate ? Q - g : g)) % Q);
             }
         });
         std::vector<u32> zq(N);

@@ -4,7 +4,7 @@
 // src/gate.cpp:133,146,172,200-202 (one call per gate inside an OpenMP task,
 // src/circuit.cpp:698-710).  Here one workgroup runs one gate bootstrap:
 //
-//   k_blind_rotate_ginx   LWE prep (ct1+ct2, folded NOTs) -> test vector -> n x AddToAcc
+//   k_blind_rotate        LWE prep (ct1+ct2, folded NOTs) -> test vector -> n x AddToAcc
 //                         (2 INTT, signed digit decomposition, 2*dG NTT, RGSW MAC with the
 //                         bootstrapping key streamed from HBM/L2, monomial multiply) -> INTT
 //   k_tail                transpose + sample extract + ModSwitch(Q->qKS) + LWE KeySwitch
@@ -247,8 +247,10 @@ __device__ __forceinline__ u32 gate_const(u32 op, u32 q) {
 // ---------------------------------------------------------------------------------------
 // OCC = workgroups the register budget is sized for per CU (2 or 3); LDS per workgroup is
 // 8 KiB twiddles + (2 + 2*DG) padded polynomials + ctprep = 52.5 KiB at N = 1024, DG = 4.
-template <int LOGN, int DG, bool LAZY, int OCC>
-__global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rotate_ginx(
+// AP = false: GINX/CGGI AddToAcc (two RGSW keys per LWE coefficient, monomial multiply, accumulate);
+// AP = true : AP/DM AddToAcc (one RGSW key per base-baseR digit of -a_i, acc is replaced).
+template <int LOGN, int DG, bool LAZY, int OCC, bool AP>
+__global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rotate(
     DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc, u32 slot_stride, u32* __restrict__ acc_out) {
     using C = Cfg<LOGN>;
     constexpr int N = C::N, NP = C::NP, E = C::E;
@@ -308,11 +310,23 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
 
     const uint2 ninv = make_uint2(P.Ninv, P.Ninv_s);
     constexpr u32 rgsw = R * 2 * N;  // words per RGSW ciphertext
-    // this thread's share of the MAC: component c, evaluation positions p0..p0+3 (loop when T < N/2)
-    for (u32 i = 0; i < n; ++i) {
-        const u32 ap = ((q - av[i]) & qm) * P.factor;  // exponent of the monomial, in [0, 2N)
-        if (ap == 0) continue;                          // X^0 - 1 = 0: AddToAcc adds nothing
-
+    // GINX: one step per LWE coefficient; AP: one step per (coefficient, base-baseR digit)
+    const u32 nsteps = AP ? n * P.dR : n;
+    for (u32 step = 0; step < nsteps; ++step) {
+        u32 ap = 0;
+        const u32* bk;
+        if constexpr (!AP) {
+            ap = ((q - av[step]) & qm) * P.factor;  // exponent of the monomial, in [0, 2N)
+            if (ap == 0) continue;                   // X^0 - 1 = 0: AddToAcc adds nothing
+            bk = P.bsk + (size_t)step * 2 * rgsw;
+        } else {
+            const u32 i = step / P.dR, k = step - i * P.dR;
+            u32 aI = (q - av[i]) & qm;
+            for (u32 t = 0; t < k; ++t) aI /= P.baseR;
+            const u32 a0 = aI % P.baseR;
+            if (a0 == 0) continue;                   // rgsw-acc-dm.cpp EvalAcc: digit 0 is skipped
+            bk = P.bsk + (((size_t)i * P.baseR + a0) * P.dR + k) * rgsw;
+        }
         // (1) two waves: INTT of acc[c], SignedDigitDecompose -> dct[2l + c] (coefficient form)
         if (wave < 2) {
             u32 x[E];
@@ -336,8 +350,31 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
         // (2) one wave per decomposed polynomial: forward NTT in place
         ntt_forward_wave<LOGN, LAZY, false>(dct + wave * NP, twf, lane, Q, P.mu32);
         __syncthreads();
-        // (3) RGSW multiply-accumulate against ek+_i, ek-_i and the two monomials
-        const u32* bk = P.bsk + (size_t)i * 2 * rgsw;
+        // (3) RGSW multiply-accumulate
+        if constexpr (AP) {
+            // acc[c] = sum_l dct[l] * ek[l][c]   (rgsw-acc-dm.cpp AddToAcc: the product REPLACES acc)
+            for (u32 item = tid; item < 2u * (N / 4); item += T) {
+                const u32 c = item / (N / 4), p0 = (item % (N / 4)) * 4;
+                const u32 pp = phys(p0);
+                const u32* bp = bk + (size_t)c * N + p0;
+                uint4 kA[R];
+#pragma unroll
+                for (u32 l = 0; l < R; ++l) kA[l] = *reinterpret_cast<const uint4*>(bp + (size_t)l * 2 * N);
+                u64 sp[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (u32 l = 0; l < R; ++l) {
+                    const uint4 d = *reinterpret_cast<const uint4*>(dct + l * NP + pp);
+                    sp[0] += (u64)d.x * kA[l].x; sp[1] += (u64)d.y * kA[l].y; sp[2] += (u64)d.z * kA[l].z; sp[3] += (u64)d.w * kA[l].w;
+                }
+                u32 a[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    a[e] = LAZY ? barrett_fold(sp[e], P.c32, Q, P.red_shift, P.red_mu) : barrett_reduce(sp[e], Q, P.red_shift, P.red_mu);
+                *reinterpret_cast<uint4*>(acc + c * NP + pp) = make_uint4(a[0], a[1], a[2], a[3]);
+            }
+            __syncthreads();
+            continue;
+        }
         // I^a' and I^-a' for I = psi^(N/2): the 4 positions p0..p0+3 sit at evaluation points whose
         // exponents differ by multiples of (N/2)*a' (brv(p0+e) = brv(p0) + {0,2,1,3}*N/4)
         const u32 a4 = ap & 3u;
@@ -419,17 +456,17 @@ size_t blind_rotate_lds_bytes(const DevParams& P) {
 
 namespace {
 using BrKernel = void (*)(DevParams, const bce_gate_desc*, u32, u32, u32*);
-template <int LOGN, int DG>
+template <int LOGN, int DG, bool AP>
 BrKernel pick_br(bool lazy, int occ) {
-    if (lazy) return occ >= 3 ? k_blind_rotate_ginx<LOGN, DG, true, 3> : k_blind_rotate_ginx<LOGN, DG, true, 2>;
-    return occ >= 3 ? k_blind_rotate_ginx<LOGN, DG, false, 3> : k_blind_rotate_ginx<LOGN, DG, false, 2>;
+    if (lazy) return occ >= 3 ? k_blind_rotate<LOGN, DG, true, 3, AP> : k_blind_rotate<LOGN, DG, true, 2, AP>;
+    return k_blind_rotate<LOGN, DG, false, 2, AP>;
 }
 template <int LOGN>
-BrKernel pick_br_dg(u32 dG, bool lazy, int occ) {
+BrKernel pick_br_dg(u32 dG, bool lazy, int occ, bool ap) {
+    // instantiated gadget sizes: every OpenFHE parameter set with Q < 2^28 has dG in {3, 4}
     switch (dG) {
-        case 2: return pick_br<LOGN, 2>(lazy, occ);
-        case 3: return pick_br<LOGN, 3>(lazy, occ);
-        case 4: return pick_br<LOGN, 4>(lazy, occ);
+        case 3: return ap ? pick_br<LOGN, 3, true>(lazy, occ) : pick_br<LOGN, 3, false>(lazy, occ);
+        case 4: return ap ? pick_br<LOGN, 4, true>(lazy, occ) : pick_br<LOGN, 4, false>(lazy, occ);
         default: return nullptr;
     }
 }
@@ -441,11 +478,12 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n
     const dim3 grid(n_desc * instances), block(64 * R);
     const size_t lds = blind_rotate_lds_bytes(P);
     const int occ = P.occupancy_target;
+    const bool ap = P.method_ap != 0;
     BrKernel kern = nullptr;
     switch (P.logN) {
-        case 9: kern = pick_br_dg<9>(P.dG, P.lazy != 0, occ); break;
-        case 10: kern = pick_br_dg<10>(P.dG, P.lazy != 0, occ); break;
-        case 11: kern = (P.dG <= 3) ? pick_br_dg<11>(P.dG, P.lazy != 0, 2) : nullptr; break;
+        case 9: kern = pick_br_dg<9>(P.dG, P.lazy != 0, occ, ap); break;
+        case 10: kern = pick_br_dg<10>(P.dG, P.lazy != 0, occ, ap); break;
+        case 11: kern = (P.dG == 3) ? pick_br_dg<11>(P.dG, P.lazy != 0, 2, ap) : nullptr; break;
         default: break;
     }
     if (!kern) return hipErrorInvalidValue;

@@ -22,6 +22,7 @@ struct DevParams {
     u32 ksk_u16;      // 1: rows are uint16_t, 0: uint32_t
     u32 gBits, dG;    // gadget: base 2^gBits, dG digits; R = 2*dG RGSW rows
     u32 baseR, dR;    // AP only
+    u32 method_ap;    // 1: AP/DM accumulator, 0: GINX/CGGI
     u32 factor;       // 2N / q
     u32 Q8p1;         // Q/8 + 1
     u32 red_shift;    // Barrett for x < 2^(2*bitlen(Q)+3): x1 = x >> red_shift

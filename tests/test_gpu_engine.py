@@ -185,5 +185,59 @@ def test_errors_are_reported_not_thrown(bce):
     with pytest.raises(bce.BceError) as e:
         c.EvalGates([(bce.AND, 0, 1, 2)])
     assert e.value.code == bce.ERR_POOL
-    with pytest.raises(bce.BceError):
-        bce.BinFHEContext(bce.STD192, bce.GINX)   # 64-bit ring modulus: not built this round
+    with pytest.raises(bce.BceError) as e:
+        bce.BinFHEContext(bce.STD192, bce.GINX)   # 37-bit ring modulus needs the 64-bit kernels: not built this round
+    assert e.value.code == bce.ERR_UNSUPPORTED
+
+
+# ---- AP (DM) method: SURVEY 8(a7) -------------------------------------------------------------
+@pytest.fixture(scope="module")
+def toy_ap(bce, orc):
+    o = orc.Oracle(orc.TOY, orc.AP)
+    o.keygen(SEED)
+    c = bce.BinFHEContext(bce.TOY, bce.AP)
+    c.import_keys(o.sk(), o.z(), o.bsk(), o.ksk())
+    return o, c
+
+
+def test_ap_toy_all_gates_bit_exact_stages(toy_ap, bce):
+    o, c = toy_ap
+    assert o.params == c.params and o.params["method"] == 1
+    cases = _gate_cases(o, base=300)
+    nb = len(cases)
+    c.pool_reserve(3 * nb)
+    c.lwe_write(np.arange(2 * nb, dtype=np.uint32), np.concatenate([np.stack([ca, cb]) for (_, _, _, ca, cb) in cases]))
+    descs = [(g, 2 * i, 2 * i + 1, 2 * nb + i) for i, (g, _, _, _, _) in enumerate(cases)]
+    acc, lweN, ks = c.debug_eval_stages(descs)
+    out = c.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32))
+    for i, (g, a, b, ca, cb) in enumerate(cases):
+        r_acc = o.blind_rotate(g, o.gate_prep(g, ca, cb))
+        assert np.array_equal(acc[i], r_acc), "AP accumulator differs, case %d" % i
+        assert np.array_equal(out[i], o.eval_bingate(g, ca, cb))
+        assert o.decrypt(out[i]) == _truth(g, a, b)
+
+
+def test_ap_keygen_matches_oracle(bce, orc):
+    o = orc.Oracle(orc.TOY, orc.AP)
+    o.keygen(4242)
+    c = bce.BinFHEContext(bce.TOY, bce.AP)
+    c.KeyGen(4242)
+    assert np.array_equal(c.export_ksk(), o.ksk())
+    assert np.array_equal(c.export_bsk(), o.bsk())
+
+
+def test_ap_std128_gate_same_seed_keys(bce, orc):
+    """STD128_AP (n=512, N=1024, baseG=2^9): keys are NOT transferred (1.6 GB); both sides derive
+    them from the same seed (keygen parity is established above), then ciphertexts must agree."""
+    o = orc.Oracle(orc.STD128_AP, orc.AP)
+    o.keygen(99)
+    c = bce.BinFHEContext(bce.STD128_AP, bce.AP)
+    c.KeyGen(99)
+    ca, cb = o.encrypt(1, 0), o.encrypt(1, 1)
+    c.pool_reserve(4)
+    c.lwe_write([0, 1], np.stack([ca, cb]))
+    c.EvalGates([(bce.NAND, 0, 1, 2), (bce.OR, 0, 1, 3)])
+    out = c.lwe_read([2, 3])
+    assert np.array_equal(out[0], o.eval_bingate(bce.NAND, ca, cb))
+    assert np.array_equal(out[1], o.eval_bingate(bce.OR, ca, cb))
+    assert list(c.Decrypt([2, 3])) == [0, 1]
