@@ -184,6 +184,13 @@ def main():
     verified = got == expect
     st = circ.stats()
 
+    traffic = None
+    try:  # HBM/fabric bytes per launch from the committed --pmc passes of this same default command
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if args.instances == 16 and args.circuit == "AES-expanded.txt" and args.paramset == "STD128_OPT" and shard_mode == 0:
+            traffic = tj["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     if rank == 0:
         bpb = cc.bytes_per_bootstrap()
         br_s = tm["blind_rotate_ms"] / 1e3
@@ -212,16 +219,18 @@ def main():
                 "host_share_of_step": round(1.0 - (tm["blind_rotate_ms"] + tm["tail_ms"]) / (elapsed * 1e3), 4),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_blind_rotate_ginx<10>",
+                "bound": "hbm", "kernel": "k_blind_rotate<10,4,lazy,GINX>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json)",
+                "algorithmic_bytes_per_launch": bpb * my_boot / max(1, tm["blind_rotate_launches"]),
                 "bytes_per_bootstrap": bpb,
                 "avg_launch_ms": tm["blind_rotate_ms"] / max(1, tm["blind_rotate_launches"]),
                 "launches": tm["blind_rotate_launches"],
                 "tail_kernel_ms_total": tm["tail_ms"],
                 "note": "achieved = algorithmic bytes (u32 BSK + u16 KSK rows + u32 cts per bootstrap) x bootstraps / "
-                        "blind-rotation kernel time from HIP events on the engine stream; the 62.8 MiB BSK stays "
-                        "resident in L2/Infinity Cache, so real HBM traffic is far below this figure",
+                        "blind-rotation kernel time from HIP events on the engine stream; the 62.8 MiB BSK is mostly served "
+                        "from L2 / Infinity Cache (traffic << algorithmic), the kernel is integer-VALU bound (84% VALU busy)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
