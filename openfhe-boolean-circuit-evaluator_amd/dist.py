@@ -33,7 +33,13 @@ class Exchange:
     def _allgather(self, nbytes, on_device):
         try:
             self.calls += 1
-            if on_device:
+            if on_device and dist.get_backend(self.group) != "nccl":
+                # no RCCL (e.g. several ranks sharing one GPU under gloo): stage through the host
+                self.host_send[:nbytes].copy_(self.dev_send[:nbytes])
+                dist.all_gather_into_tensor(self.host_recv[: nbytes * self.world], self.host_send[:nbytes], group=self.group)
+                self.dev_recv[: nbytes * self.world].copy_(self.host_recv[: nbytes * self.world])
+                torch.cuda.synchronize(self.device)
+            elif on_device:
                 # engine stream was synchronized by the runtime before this call
                 dist.all_gather_into_tensor(self.dev_recv[: nbytes * self.world], self.dev_send[:nbytes], group=self.group)
                 torch.cuda.synchronize(self.device)
