@@ -60,7 +60,10 @@ struct bce_ctx {
     DevParams P{};
     // device tables / keys
     uint2* d_twf = nullptr;
-    u32* d_bsk = nullptr;
+    void* d_bsk = nullptr;       // u32 words (Q < 2^28) or u64 words (is64)
+    ulonglong2* d_tw64 = nullptr;
+    bool is64 = false;
+    size_t wbytes = 4;
     void* d_ksk = nullptr;
     u64 bsk_polys = 0;
     bool have_keys = false;
@@ -71,7 +74,7 @@ struct bce_ctx {
     u32* d_pool = nullptr;
     u32 pool_slots = 0;
     // work buffers
-    u32* d_acc = nullptr;
+    void* d_acc = nullptr;
     size_t acc_cap = 0;  // bootstraps
     static constexpr int kRing = 4;
     bce_gate_desc* d_descs[kRing] = {nullptr, nullptr, nullptr, nullptr};
@@ -111,7 +114,7 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     if (N < 512 || N > 2048 || (N & (N - 1))) { g_create_error = "ring dimension N must be 512, 1024 or 2048"; return BCE_ERR_UNSUPPORTED; }
     if ((q & (q - 1)) || q > 2 * (u64)N || q < 8) { g_create_error = "LWE modulus q must be a power of two dividing 2N"; return BCE_ERR_ARG; }
     if (!is_prime_u64(Q) || (Q - 1) % (2ull * N)) { g_create_error = "Q must be a prime = 1 mod 2N"; return BCE_ERR_ARG; }
-    if (Q >= (1ull << 28)) { g_create_error = "ring modulus Q >= 2^28 needs the 64-bit kernels (not built in this round)"; return BCE_ERR_UNSUPPORTED; }
+    if (Q >= (1ull << 40)) { g_create_error = "ring modulus Q must be below 2^40"; return BCE_ERR_UNSUPPORTED; }
     if (baseG & (baseG - 1)) { g_create_error = "gadget base must be a power of two"; return BCE_ERR_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -128,7 +131,10 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     c->dKS = digit_count((double)c->qKS, (double)baseKS);
     c->dG = digit_count((double)Q, (double)baseG);
     c->dR = digit_count((double)q, (double)baseR);
+    c->is64 = Q >= (1ull << 28);
+    c->wbytes = c->is64 ? 8 : 4;
     if (c->dG < 3 || c->dG > 4 || (N == 2048 && c->dG != 3)) { g_create_error = "gadget digit count must be 3 or 4 (3 for N = 2048)"; return BCE_ERR_UNSUPPORTED; }
+    if (c->is64 && !(c->dG == 3 || (c->dG == 4 && N == 512))) { g_create_error = "64-bit path: gadget digit count must be 3"; return BCE_ERR_UNSUPPORTED; }
     if (c->qKS > 0xFFFFFFFFull) { g_create_error = "qKS must fit 32 bits"; return BCE_ERR_UNSUPPORTED; }
     c->psi = min_primitive_root(Q, 2ull * N);
 
@@ -140,7 +146,7 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     u64 p = 1;
     for (u32 i = 0; i < N; ++i) {
         u32 r = bit_reverse(i, (int)c->logN);
-        twf[r] = make_uint2((u32)p, (u32)(((u128)p << 32) / Q));
+        twf[r] = c->is64 ? make_uint2(0, 0) : make_uint2((u32)p, (u32)(((u128)p << 32) / Q));
         p = mul_mod(p, c->psi, Q);
     }
     if (hipMalloc(&c->d_twf, sizeof(uint2) * N) != hipSuccess) {
@@ -161,10 +167,10 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     P.Q8p1 = (u32)(Q / 8 + 1);
     int bq = bit_length(Q);
     P.red_shift = (u32)std::max(2 * bq + 3 - 32, 0);
-    P.red_mu = (u32)((((u128)1) << (32 + P.red_shift)) / Q);
+    P.red_mu = c->is64 ? 0 : (u32)((((u128)1) << (32 + P.red_shift)) / Q);
     u64 ninv = pow_mod(N, Q - 2, Q);
     P.Ninv = (u32)ninv;
-    P.Ninv_s = (u32)(((u128)ninv << 32) / Q);
+    P.Ninv_s = c->is64 ? 0 : (u32)(((u128)ninv << 32) / Q);
     P.mu32 = (u32)((((u64)1) << 32) / Q);
     P.c32 = (u32)((((u64)1) << 32) % Q);
     {
@@ -189,11 +195,31 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         u64 I = pow_mod(c->psi, N / 2, Q), v = 1;
         for (int k = 0; k < 4; ++k) {
             P.I4[k] = (u32)v;
-            P.I4s[k] = (u32)(((u128)v << 32) / Q);
+            P.I4s[k] = c->is64 ? 0 : (u32)(((u128)v << 32) / Q);
             v = mul_mod(v, I, Q);
         }
     }
     P.tw_f = c->d_twf;
+    P.is64 = c->is64 ? 1 : 0;
+    P.Q64 = Q;
+    P.Q8p1_64 = Q / 8 + 1;
+    P.mu64 = (u64)((((u128)1) << 64) / Q);
+    P.c64 = (u64)((((u128)1) << 64) % Q);
+    P.Ninv64 = ninv;
+    P.Ninv64_s = (u64)(((u128)ninv << 64) / Q);
+    if (c->is64) {
+        std::vector<ulonglong2> tw64(N);
+        u64 pw = 1;
+        for (u32 i = 0; i < N; ++i) {
+            tw64[bit_reverse(i, (int)c->logN)] = make_ulonglong2(pw, (u64)(((u128)pw << 64) / Q));
+            pw = mul_mod(pw, c->psi, Q);
+        }
+        if (hipMalloc(&c->d_tw64, sizeof(ulonglong2) * N) != hipSuccess) { g_create_error = "hipMalloc(twiddles64) failed"; return BCE_ERR_HIP; }
+        hipMemcpy(c->d_tw64, tw64.data(), sizeof(ulonglong2) * N, hipMemcpyHostToDevice);
+        P.tw64 = c->d_tw64;
+        if (blind_rotate64_lds_bytes(P) > 160 * 1024) { g_create_error = "64-bit path: polynomials do not fit the 160 KiB LDS"; return BCE_ERR_UNSUPPORTED; }
+        P.lazy = 1;
+    }
     P.pool_stride = n + 1;
     *out = c.release();
     return BCE_OK;
@@ -207,13 +233,14 @@ u64 rgsw_rows_total(const bce_ctx* c) {
 int alloc_keys(bce_ctx* c) {
     if (!c->d_bsk) {
         c->bsk_polys = rgsw_rows_total(c) * 2;
-        HIP_TRY(c, hipMalloc(&c->d_bsk, sizeof(u32) * c->bsk_polys * c->N));
+        HIP_TRY(c, hipMalloc(&c->d_bsk, c->wbytes * c->bsk_polys * c->N));
     }
     if (!c->d_ksk) {
         size_t rows = (size_t)c->N * c->baseKS * c->dKS;
         HIP_TRY(c, hipMalloc(&c->d_ksk, rows * c->P.ksk_stride * (c->P.ksk_u16 ? 2 : 4)));
     }
-    c->P.bsk = c->d_bsk;
+    c->P.bsk = static_cast<const u32*>(c->d_bsk);
+    c->P.bsk64 = static_cast<const u64*>(c->d_bsk);
     c->P.ksk = c->d_ksk;
     return BCE_OK;
 }
@@ -252,7 +279,7 @@ int ensure_acc(bce_ctx* c, size_t boots) {
     if (c->d_acc) hipFree(c->d_acc);
     c->d_acc = nullptr;
     size_t cap = std::max(boots, c->acc_cap * 2);
-    HIP_TRY(c, hipMalloc(&c->d_acc, cap * 2 * c->N * sizeof(u32)));
+    HIP_TRY(c, hipMalloc(&c->d_acc, cap * 2 * c->N * c->wbytes));
     c->acc_cap = cap;
     return BCE_OK;
 }
@@ -304,6 +331,103 @@ void drain_timing(bce_ctx* c) {
     c->pending.clear();
 }
 
+
+// ---- word-size generic device helpers (u32: kernels.hip, u64: kernels64.hip) -----------------
+int dev_ntt(bce_ctx* c, void* polys, u64 count, int inverse) {
+    // count may exceed what one launch indexes comfortably; split in slabs of 2^20 polys
+    const u64 slab = 1u << 20;
+    for (u64 o = 0; o < count; o += slab) {
+        const u32 cnt = (u32)std::min<u64>(slab, count - o);
+        if (c->is64) HIP_TRY(c, launch_ntt_batch64(c->P, static_cast<u64*>(polys) + o * c->N, cnt, inverse, c->stream));
+        else HIP_TRY(c, launch_ntt_batch(c->P, static_cast<u32*>(polys) + o * c->N, cnt, inverse, c->stream));
+    }
+    return BCE_OK;
+}
+
+// Bootstrapping key.  GINX: ek[i][0] = RGSW(s_i == 1), ek[i][1] = RGSW(s_i == -1)
+// (rgsw-acc-cggi.cpp KeyGenAcc).  AP: ek[i][v][k] = RGSW(X^{s_i * v * baseR^k * 2N/q}), v >= 1
+// (rgsw-acc-dm.cpp KeyGenAcc; the v = 0 slots stay zero and are never read).
+// The host draws (a, e) per row and adds the gadget; the device does the NTTs and a*z.
+// Rows are produced in chunks so that host staging stays below ~0.75 GB whatever the key size
+// (STD192/AP: 12.9 GB of key).
+template <typename W>
+int keygen_bsk(bce_ctx* c, const GaussSampler& gauss) {
+    const u32 N = c->N, R = 2 * c->dG;
+    const u64 Q = c->Q;
+    const u64 rows = rgsw_rows_total(c);
+    const u64 chunk = std::max<u64>(R, std::min<u64>(rows, ((u64)256 << 20) / ((u64)N * sizeof(W))) / R * R);
+    std::vector<W> bsk(chunk * 2 * N), ta(chunk * N);
+    std::vector<u64> gpow(c->dG);
+    { u64 v = 1; for (u32 i = 0; i < c->dG; ++i) { gpow[i] = v; v = mul_mod(v, c->baseG, Q); } }
+    std::vector<W> zq(N);
+    for (u32 k = 0; k < N; ++k) zq[k] = (W)lift_signed(c->z[k], Q);
+    W *d_ta = nullptr, *d_z = nullptr;
+    HIP_TRY(c, hipMalloc(&d_ta, chunk * N * sizeof(W)));
+    HIP_TRY(c, hipMalloc(&d_z, N * sizeof(W)));
+    HIP_TRY(c, hipMemcpy(d_z, zq.data(), N * sizeof(W), hipMemcpyHostToDevice));
+    int rc = dev_ntt(c, d_z, 1, 0);
+    if (rc) return rc;
+    const u64* gp = gpow.data();
+    const int32_t* s = c->s.data();
+    const uint8_t* sd = c->seed;
+    const bool ap = c->method == BCE_AP;
+    const u32 BR = c->baseR, DR = c->dR;
+    const int64_t qq = (int64_t)c->q;
+    W* dev = static_cast<W*>(c->d_bsk);
+    for (u64 r0 = 0; r0 < rows; r0 += chunk) {
+        const u64 cnt = std::min(chunk, rows - r0);
+        std::fill(bsk.begin(), bsk.begin() + cnt * 2 * N, (W)0);
+        std::fill(ta.begin(), ta.begin() + cnt * N, (W)0);
+        W* bp = bsk.data();
+        W* tp = ta.data();
+        parallel_for(cnt, [=, &gauss](size_t local) {
+            const u64 rowid = r0 + local;
+            const u32 r = (u32)(rowid % R);
+            const u64 ek = rowid / R;
+            bool one;
+            u32 mm = 0;
+            bool negate = false;
+            if (!ap) {
+                const u32 i = (u32)(ek / 2), key = (u32)(ek % 2);   // ek = i*2 + key
+                one = key == 0 ? (s[i] == 1) : (s[i] == -1);
+            } else {
+                const u32 k = (u32)(ek % DR), v = (u32)((ek / DR) % BR), i = (u32)(ek / DR / BR);
+                if (v == 0) return;
+                int64_t pw = 1;
+                for (u32 t = 0; t < k; ++t) pw *= BR;
+                const int64_t m = (int64_t)s[i] * (int64_t)v * pw;
+                int64_t e = (((m % qq) + qq) % qq) * (int64_t)(2 * N / qq);
+                if (e >= (int64_t)N) { e -= N; negate = true; }
+                mm = (u32)e;
+                one = true;
+            }
+            ChaChaStream st(sd, kDomBSK, rowid);
+            W* a = bp + (local * 2 + 0) * N;
+            W* b = bp + (local * 2 + 1) * N;
+            W* t = tp + local * N;
+            for (u32 k = 0; k < N; ++k) t[k] = a[k] = (W)draw_uniform(st, Q);
+            for (u32 k = 0; k < N; ++k) b[k] = (W)lift_signed(gauss.draw(st), Q);
+            if (one) {
+                W* tgt = (r & 1) ? b : a;        // row 2j: column 0, row 2j+1: column 1
+                const u64 g = gp[r >> 1];
+                tgt[mm] = (W)(((u64)tgt[mm] + (negate ? Q - g : g)) % Q);
+            }
+        });
+        W* dst = dev + r0 * 2 * N;
+        HIP_TRY(c, hipMemcpy(dst, bsk.data(), cnt * 2 * N * sizeof(W), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_ta, ta.data(), cnt * N * sizeof(W), hipMemcpyHostToDevice));
+        if ((rc = dev_ntt(c, dst, cnt * 2, 0))) return rc;
+        if ((rc = dev_ntt(c, d_ta, cnt, 0))) return rc;
+        // b-column (odd polys) += NTT(a) * NTT(z)
+        if constexpr (sizeof(W) == 8) HIP_TRY(c, launch_pointwise_mac64(c->P, (u64*)dst + N, (const u64*)d_ta, (const u64*)d_z, (u32)cnt, 2, c->stream));
+        else HIP_TRY(c, launch_pointwise_mac(c->P, (u32*)dst + N, (const u32*)d_ta, (const u32*)d_z, (u32)cnt, 2, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    hipFree(d_ta);
+    hipFree(d_z);
+    return BCE_OK;
+}
+
 int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances, u32 slot_stride, u64* dbg_acc,
               u64* dbg_lweN, u64* dbg_ks) {
     if (n_desc == 0 || instances == 0) return BCE_OK;
@@ -333,7 +457,8 @@ int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances,
         if (rc) return rc;
         EventPair e0 = get_events(c, 0);
         hipEventRecord(e0.a, c->stream);
-        HIP_TRY(c, launch_blind_rotate(c->P, dd, (u32)boot.size(), instances, slot_stride, c->d_acc, c->stream));
+        if (c->is64) HIP_TRY(c, launch_blind_rotate64(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u64*>(c->d_acc), c->stream));
+        else HIP_TRY(c, launch_blind_rotate(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u32*>(c->d_acc), c->stream));
         hipEventRecord(e0.b, c->stream);
         c->pending.push_back(e0);
         u32 *d_lweN = nullptr, *d_ks = nullptr;
@@ -357,7 +482,8 @@ int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances,
                 for (size_t i = 0; i < words; ++i) dst[i] = tmp[i];
                 return BCE_OK;
             };
-            if (dbg_acc && (rc = fetch(c->d_acc, nb * 2 * c->N, dbg_acc))) return rc;
+            if (dbg_acc && c->is64) HIP_TRY(c, hipMemcpy(dbg_acc, c->d_acc, nb * 2 * c->N * 8, hipMemcpyDeviceToHost));
+            if (dbg_acc && !c->is64 && (rc = fetch(static_cast<const u32*>(c->d_acc), nb * 2 * c->N, dbg_acc))) return rc;
             if (dbg_lweN && (rc = fetch(d_lweN, nb * (c->N + 1), dbg_lweN))) return rc;
             if (dbg_ks && (rc = fetch(d_ks, nb * (c->n + 1), dbg_ks))) return rc;
             if (d_lweN) hipFree(d_lweN);
@@ -407,7 +533,7 @@ void bce_ctx_destroy(bce_ctx* c) {
         if (c->h_descs[i]) hipHostFree(c->h_descs[i]);
         if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
     }
-    hipFree(c->d_twf); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc);
+    hipFree(c->d_twf); hipFree(c->d_tw64); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -473,73 +599,8 @@ int bce_keygen(bce_ctx* c, const uint8_t seed[32]) {
         if (rc) return rc;
     }
 
-    // Bootstrapping key.  GINX: ek[i][0] = RGSW(s_i == 1), ek[i][1] = RGSW(s_i == -1)
-    // (rgsw-acc-cggi.cpp KeyGenAcc).  AP: ek[i][v][k] = RGSW(X^{s_i * v * baseR^k * 2N/q}), v >= 1
-    // (rgsw-acc-dm.cpp KeyGenAcc; the v = 0 slots stay zero and are never read).
-    // Host draws (a, e) per row and adds the gadget; the device does the NTTs and a*z.
-    {
-        const u32 R = 2 * c->dG;
-        const u64 rows = rgsw_rows_total(c);
-        std::vector<u32> bsk(rows * 2 * N, 0), ta(rows * N, 0);
-        std::vector<u64> gpow(c->dG);
-        { u64 v = 1; for (u32 i = 0; i < c->dG; ++i) { gpow[i] = v; v = mul_mod(v, c->baseG, Q); } }
-        u32* bp = bsk.data();
-        u32* tp = ta.data();
-        const u64* gp = gpow.data();
-        const int32_t* s = c->s.data();
-        const uint8_t* sd = c->seed;
-        const bool ap = c->method == BCE_AP;
-        const u32 BR = c->baseR, DR = c->dR;
-        const int64_t qq = (int64_t)c->q;
-        parallel_for(rows, [=, &gauss](size_t rowid) {
-            const u32 r = (u32)(rowid % R);
-            const u64 ek = rowid / R;
-            bool one;
-            u32 mm = 0;
-            bool negate = false;
-            if (!ap) {
-                const u32 i = (u32)(ek / 2), key = (u32)(ek % 2);   // ek = i*2 + key
-                one = key == 0 ? (s[i] == 1) : (s[i] == -1);
-            } else {
-                const u32 k = (u32)(ek % DR), v = (u32)((ek / DR) % BR), i = (u32)(ek / DR / BR);
-                if (v == 0) return;
-                int64_t pw = 1;
-                for (u32 t = 0; t < k; ++t) pw *= BR;
-                const int64_t m = (int64_t)s[i] * (int64_t)v * pw;
-                int64_t e = (((m % qq) + qq) % qq) * (int64_t)(2 * N / qq);
-                if (e >= (int64_t)N) { e -= N; negate = true; }
-                mm = (u32)e;
-                one = true;
-            }
-            ChaChaStream st(sd, kDomBSK, rowid);
-            u32* a = bp + (rowid * 2 + 0) * N;
-            u32* b = bp + (rowid * 2 + 1) * N;
-            u32* t = tp + rowid * N;
-            for (u32 k = 0; k < N; ++k) t[k] = a[k] = (u32)draw_uniform(st, Q);
-            for (u32 k = 0; k < N; ++k) b[k] = (u32)lift_signed(gauss.draw(st), Q);
-            if (one) {
-                u32* tgt = (r & 1) ? b : a;      // row 2j: column 0, row 2j+1: column 1
-                const u64 g = gp[r >> 1];
-                tgt[mm] = (u32)((tgt[mm] + (negate ? Q - g : g)) % Q);
-            }
-        });
-        std::vector<u32> zq(N);
-        for (u32 k = 0; k < N; ++k) zq[k] = (u32)lift_signed(c->z[k], Q);
-        u32 *d_ta = nullptr, *d_z = nullptr;
-        HIP_TRY(c, hipMalloc(&d_ta, ta.size() * 4));
-        HIP_TRY(c, hipMalloc(&d_z, N * 4));
-        HIP_TRY(c, hipMemcpy(c->d_bsk, bsk.data(), bsk.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(d_ta, ta.data(), ta.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(d_z, zq.data(), N * 4, hipMemcpyHostToDevice));
-        HIP_TRY(c, launch_ntt_batch(c->P, c->d_bsk, (u32)(rows * 2), 0, c->stream));
-        HIP_TRY(c, launch_ntt_batch(c->P, d_ta, (u32)rows, 0, c->stream));
-        HIP_TRY(c, launch_ntt_batch(c->P, d_z, 1, 0, c->stream));
-        // b-column (odd polys) += NTT(a) * NTT(z)
-        HIP_TRY(c, launch_pointwise_mac(c->P, c->d_bsk + N, d_ta, d_z, (u32)rows, 2, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        hipFree(d_ta);
-        hipFree(d_z);
-    }
+    rc = c->is64 ? keygen_bsk<u64>(c, gauss) : keygen_bsk<u32>(c, gauss);
+    if (rc) return rc;
     c->have_keys = true;
     return BCE_OK;
 }
@@ -553,14 +614,25 @@ int bce_import_keys(bce_ctx* c, const int32_t* s, const int32_t* z, const uint64
     if (rc) return rc;
     c->s.assign(s, s + c->n);
     if (z) c->z.assign(z, z + c->N); else c->z.clear();
-    std::vector<u32> tmp(bsk_words);
-    for (u64 i = 0; i < bsk_words; ++i) {
-        if (bsk[i] >= c->Q) return c->fail(BCE_ERR_ARG, "bsk word %llu not reduced mod Q", (unsigned long long)i);
-        tmp[i] = (u32)bsk[i];
+    {   // coefficient-domain words -> device words, chunked; then NTT in place on the device
+        const u64 chunk = (u64)64 << 20;
+        std::vector<u32> tmp32;
+        for (u64 o = 0; o < bsk_words; o += chunk) {
+            const u64 cnt = std::min(chunk, bsk_words - o);
+            for (u64 i = 0; i < cnt; ++i)
+                if (bsk[o + i] >= c->Q) return c->fail(BCE_ERR_ARG, "bsk word %llu not reduced mod Q", (unsigned long long)(o + i));
+            if (c->is64) {
+                HIP_TRY(c, hipMemcpy(static_cast<u64*>(c->d_bsk) + o, bsk + o, cnt * 8, hipMemcpyHostToDevice));
+            } else {
+                tmp32.resize(cnt);
+                for (u64 i = 0; i < cnt; ++i) tmp32[i] = (u32)bsk[o + i];
+                HIP_TRY(c, hipMemcpy(static_cast<u32*>(c->d_bsk) + o, tmp32.data(), cnt * 4, hipMemcpyHostToDevice));
+            }
+        }
+        rc = dev_ntt(c, c->d_bsk, bsk_words / c->N, 0);
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    HIP_TRY(c, hipMemcpy(c->d_bsk, tmp.data(), bsk_words * 4, hipMemcpyHostToDevice));
-    HIP_TRY(c, launch_ntt_batch(c->P, c->d_bsk, (u32)(bsk_words / c->N), 0, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     rc = upload_ksk(c, ksk);
     if (rc) return rc;
     c->have_keys = true;
@@ -579,15 +651,26 @@ int bce_export_bsk(bce_ctx* c, uint64_t* bsk) {
     if (!c->have_keys) return c->fail(BCE_ERR_NO_KEYS, "no keys");
     HIP_TRY(c, hipSetDevice(c->device));
     const u64 words = bce_bsk_words(c);
-    u32* d_tmp = nullptr;
-    HIP_TRY(c, hipMalloc(&d_tmp, words * 4));
-    HIP_TRY(c, hipMemcpyAsync(d_tmp, c->d_bsk, words * 4, hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(c, launch_ntt_batch(c->P, d_tmp, (u32)(words / c->N), 1, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    std::vector<u32> tmp(words);
-    HIP_TRY(c, hipMemcpy(tmp.data(), d_tmp, words * 4, hipMemcpyDeviceToHost));
+    const u64 chunk_polys = std::max<u64>(1, ((u64)256 << 20) / ((u64)c->N * c->wbytes));
+    void* d_tmp = nullptr;
+    HIP_TRY(c, hipMalloc(&d_tmp, chunk_polys * c->N * c->wbytes));
+    std::vector<u32> tmp32;
+    for (u64 p0 = 0; p0 < words / c->N; p0 += chunk_polys) {
+        const u64 cnt = std::min(chunk_polys, words / c->N - p0), w = cnt * c->N;
+        const char* src = static_cast<const char*>(c->d_bsk) + p0 * c->N * c->wbytes;
+        HIP_TRY(c, hipMemcpyAsync(d_tmp, src, w * c->wbytes, hipMemcpyDeviceToDevice, c->stream));
+        int rc = dev_ntt(c, d_tmp, cnt, 1);
+        if (rc) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->is64) {
+            HIP_TRY(c, hipMemcpy(bsk + p0 * c->N, d_tmp, w * 8, hipMemcpyDeviceToHost));
+        } else {
+            tmp32.resize(w);
+            HIP_TRY(c, hipMemcpy(tmp32.data(), d_tmp, w * 4, hipMemcpyDeviceToHost));
+            for (u64 i = 0; i < w; ++i) bsk[p0 * c->N + i] = tmp32[i];
+        }
+    }
     hipFree(d_tmp);
-    for (u64 i = 0; i < words; ++i) bsk[i] = tmp[i];
     return BCE_OK;
 }
 
@@ -766,8 +849,11 @@ int bce_timing_get(bce_ctx* c, bce_timing* out) {
 
 uint64_t bce_bytes_per_bootstrap(const bce_ctx* c) {
     if (!c) return 0;
-    // w_bsk*[n*2*(2dG)*2*N] + w_ks*[N*dKS*(n+1)] + w_ct*[3(n+1)] at this build's widths
-    const u64 bsk = 4ull * c->n * 2 * (2 * c->dG) * 2 * c->N;
+    // w_bsk*[RGSWs touched * (2dG)*2*N] + w_ks*[N*dKS*(n+1)] + w_ct*[3(n+1)] at this build's widths.
+    // GINX touches 2 RGSW ciphertexts per LWE coefficient, AP one per non-zero base-baseR digit
+    // (dR * (baseR-1)/baseR on average).
+    const double rgsws = c->method == BCE_AP ? (double)c->n * c->dR * (c->baseR - 1) / c->baseR : 2.0 * c->n;
+    const u64 bsk = (u64)((double)c->wbytes * rgsws * (2 * c->dG) * 2 * c->N);
     const u64 ks = (c->P.ksk_u16 ? 2ull : 4ull) * c->N * c->dKS * (c->n + 1);
     const u64 ct = 4ull * 3 * (c->n + 1);
     return bsk + ks + ct;
@@ -811,19 +897,28 @@ int bce_debug_ntt(bce_ctx* c, uint64_t* polys, uint32_t count, int inverse) {
     if (!c || !polys) return BCE_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t words = (size_t)count * c->N;
-    std::vector<u32> tmp(words);
-    for (size_t i = 0; i < words; ++i) {
+    for (size_t i = 0; i < words; ++i)
         if (polys[i] >= c->Q) return c->fail(BCE_ERR_ARG, "poly word not reduced mod Q");
-        tmp[i] = (u32)polys[i];
+    void* d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, words * c->wbytes));
+    std::vector<u32> tmp;
+    if (c->is64) {
+        HIP_TRY(c, hipMemcpy(d, polys, words * 8, hipMemcpyHostToDevice));
+    } else {
+        tmp.resize(words);
+        for (size_t i = 0; i < words; ++i) tmp[i] = (u32)polys[i];
+        HIP_TRY(c, hipMemcpy(d, tmp.data(), words * 4, hipMemcpyHostToDevice));
     }
-    u32* d = nullptr;
-    HIP_TRY(c, hipMalloc(&d, words * 4));
-    HIP_TRY(c, hipMemcpy(d, tmp.data(), words * 4, hipMemcpyHostToDevice));
-    HIP_TRY(c, launch_ntt_batch(c->P, d, count, inverse, c->stream));
+    int rc = dev_ntt(c, d, count, inverse);
+    if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(tmp.data(), d, words * 4, hipMemcpyDeviceToHost));
+    if (c->is64) {
+        HIP_TRY(c, hipMemcpy(polys, d, words * 8, hipMemcpyDeviceToHost));
+    } else {
+        HIP_TRY(c, hipMemcpy(tmp.data(), d, words * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < words; ++i) polys[i] = tmp[i];
+    }
     hipFree(d);
-    for (size_t i = 0; i < words; ++i) polys[i] = tmp[i];
     return BCE_OK;
 }
 

@@ -498,29 +498,32 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n
 // ---------------------------------------------------------------------------------------
 // LWEEncryptionScheme::RoundqQ restated with the same three IEEE double operations
 // (compiled with -ffp-contract=off): floor(0.5 + double(v) * double(q) / double(Q)) mod q
-__device__ __forceinline__ u32 round_qQ(u32 v, u32 q, u32 Qfrom) {
+__device__ __forceinline__ u32 round_qQ(u64 v, u32 q, u64 Qfrom) {
     double t = (double)v * (double)q;
     t = t / (double)Qfrom;
     u64 r = (u64)floor(0.5 + t);
     return (u32)(r >= q ? r - q : r);
 }
 
-template <typename KT, typename ACC>
+// KT = key-switch key element type, ACC = its accumulator, AW = accumulator word of the blind rotation
+template <typename KT, typename ACC, typename AW>
 __global__ __launch_bounds__(256) void k_tail(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
-                                              u32 slot_stride, const u32* __restrict__ acc_in,
+                                              u32 slot_stride, const AW* __restrict__ acc_in,
                                               u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
     extern __shared__ __align__(16) u32 smem[];
-    const u32 N = P.N, n = P.n, Q = P.Q, qKS = P.qKS, B = P.baseKS, D = P.dKS;
+    const u32 N = P.N, n = P.n, qKS = P.qKS, B = P.baseKS, D = P.dKS;
+    const u64 Q = sizeof(AW) == 8 ? P.Q64 : (u64)P.Q;
+    const u64 Q8p1 = sizeof(AW) == 8 ? P.Q8p1_64 : (u64)P.Q8p1;
     u32* rowidx = smem;  // [N*D] row number (i*B + digit)*D + j
     __shared__ u32 s_b;
     const u32 tid = threadIdx.x, T = blockDim.x;
-    const u32* a0 = acc_in + (size_t)blockIdx.x * 2 * N;
-    const u32* a1 = a0 + N;
+    const AW* a0 = acc_in + (size_t)blockIdx.x * 2 * N;
+    const AW* a1 = a0 + N;
 
     // Transpose (X -> X^-1) of acc[0]: a'_0 = a_0, a'_{N-i} = -a_i ; then ModSwitch(Q -> qKS)
     for (u32 i = tid; i < N; i += T) {
-        u32 src = (i == 0) ? a0[0] : a0[N - i];
-        u32 v = (i == 0) ? src : (src ? Q - src : 0u);
+        u64 src = (i == 0) ? a0[0] : a0[N - i];
+        u64 v = (i == 0) ? src : (src ? Q - src : 0);
         u32 at = round_qQ(v, qKS, Q);
         if (dbg_lweN) dbg_lweN[(size_t)blockIdx.x * (N + 1) + i] = at;
         for (u32 j = 0; j < D; ++j) {
@@ -529,11 +532,11 @@ __global__ __launch_bounds__(256) void k_tail(DevParams P, const bce_gate_desc* 
         }
     }
     if (tid == 0) {
-        u32 b = a1[0] + P.Q8p1;
+        u64 b = (u64)a1[0] + Q8p1;
         b = b >= Q ? b - Q : b;
-        b = round_qQ(b, qKS, Q);
-        s_b = b;
-        if (dbg_lweN) dbg_lweN[(size_t)blockIdx.x * (N + 1) + N] = b;
+        u32 bs = round_qQ(b, qKS, Q);
+        s_b = bs;
+        if (dbg_lweN) dbg_lweN[(size_t)blockIdx.x * (N + 1) + N] = bs;
     }
     __syncthreads();
 
@@ -562,13 +565,17 @@ __global__ __launch_bounds__(256) void k_tail(DevParams P, const bce_gate_desc* 
 }
 
 hipError_t launch_tail(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
-                       const u32* acc_in, u32* dbg_lweN, u32* dbg_ks, hipStream_t s) {
+                       const void* acc_in, u32* dbg_lweN, u32* dbg_ks, hipStream_t s) {
     const dim3 grid(n_desc * instances), block(256);
     const size_t lds = (size_t)P.N * P.dKS * sizeof(u32);
-    if (P.ksk_u16) {
-        hipLaunchKernelGGL((k_tail<uint16_t, u32>), grid, block, lds, s, P, d, n_desc, slot_stride, acc_in, dbg_lweN, dbg_ks);
+    if (P.is64) {
+        const u64* a = static_cast<const u64*>(acc_in);
+        if (P.ksk_u16) hipLaunchKernelGGL((k_tail<uint16_t, u32, u64>), grid, block, lds, s, P, d, n_desc, slot_stride, a, dbg_lweN, dbg_ks);
+        else hipLaunchKernelGGL((k_tail<u32, u64, u64>), grid, block, lds, s, P, d, n_desc, slot_stride, a, dbg_lweN, dbg_ks);
     } else {
-        hipLaunchKernelGGL((k_tail<u32, u64>), grid, block, lds, s, P, d, n_desc, slot_stride, acc_in, dbg_lweN, dbg_ks);
+        const u32* a = static_cast<const u32*>(acc_in);
+        if (P.ksk_u16) hipLaunchKernelGGL((k_tail<uint16_t, u32, u32>), grid, block, lds, s, P, d, n_desc, slot_stride, a, dbg_lweN, dbg_ks);
+        else hipLaunchKernelGGL((k_tail<u32, u64, u32>), grid, block, lds, s, P, d, n_desc, slot_stride, a, dbg_lweN, dbg_ks);
     }
     return hipGetLastError();
 }

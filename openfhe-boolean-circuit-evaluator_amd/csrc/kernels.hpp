@@ -36,6 +36,14 @@ struct DevParams {
     const uint2* tw_f;  // [N] (psi^brv(i), shoup), index m+i as in the CT forward NTT; the inverse
                         // transform derives psi^-k = -psi^(N-k) from the same table
     const u32* bsk;     // EVALUATION domain, GINX [n][2][R][2][N]; AP [n][baseR][dR][R][2][N]
+    // ---- 64-bit ring modulus path (kernels64.hip), used when is64 != 0 (Q >= 2^28) ----
+    u32 is64;
+    u64 Q64, Q8p1_64;
+    u64 mu64;           // floor(2^64 / Q)
+    u64 c64;            // 2^64 mod Q
+    u64 Ninv64, Ninv64_s;
+    const ulonglong2* tw64;  // [N] (psi^brv(i), floor(. * 2^64 / Q))
+    const u64* bsk64;
     const void* ksk;    // [N][baseKS][dKS][ksk_stride]
     u32* pool;          // [slots][pool_stride]
     u32 pool_stride;
@@ -51,7 +59,15 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d_descs,
 // extract + ModSwitch(Q->qKS) + KeySwitch + ModSwitch(qKS->q) -> pool[out]
 // dbg_lweN: u32 [n_boot][N+1] or null; dbg_ks: u32 [n_boot][n+1] or null
 hipError_t launch_tail(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances, u32 slot_stride,
-                       const u32* acc_in, u32* dbg_lweN, u32* dbg_ks, hipStream_t s);
+                       const void* acc_in /* u32 or u64 words by P.is64 */, u32* dbg_lweN, u32* dbg_ks, hipStream_t s);
+
+// 64-bit-modulus counterparts (kernels64.hip)
+size_t blind_rotate64_lds_bytes(const DevParams& P);
+hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances,
+                                 u32 slot_stride, u64* acc_out, hipStream_t s);
+hipError_t launch_ntt_batch64(const DevParams& P, u64* polys, u32 count, int inverse, hipStream_t s);
+hipError_t launch_pointwise_mac64(const DevParams& P, u64* b, const u64* a, const u64* z, u32 count, u32 b_step,
+                                  hipStream_t s);
 
 // EvalNOT / COPY over pool slots
 hipError_t launch_lwe_unary(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances,

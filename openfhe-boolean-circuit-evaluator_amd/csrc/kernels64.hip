@@ -1,0 +1,448 @@
+// kernels64.hip -- 64-bit-modulus variants (ring modulus 2^28 <= Q < 2^62, e.g. STD192's 37-bit Q)
+// of the blind-rotation / NTT kernels in kernels.hip.
+//
+// Same organisation as the 32-bit path (one workgroup per gate bootstrap, one 64-wide wavefront
+// per RGSW row polynomial, E = N/64 coefficients per lane in registers, log2(E) radix-2 stages
+// per register pass, LDS re-shuffles between passes) and the same reference hot path
+// (EvalBinGate, src/gate.cpp:133,146,172,200-202).  Differences: words are u64; the 64-bit
+// headroom makes BOTH transforms fully lazy (no per-stage correction at all); RGSW MAC sums are
+// accumulated in 128 bits and reduced once; twiddles are read from global memory (L1/L2) because
+// (2 + 2*dG) padded polynomials of N = 2048 u64 words already take 139 KiB of the 160 KiB LDS.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace bce {
+namespace w64 {
+
+__device__ __forceinline__ u64 csub(u64 x, u64 m) { return min(x, x - m); }
+
+// y * w mod Q lazily, result in [0, 2Q) for any 64-bit y; w = (value, floor(value * 2^64 / Q))
+__device__ __forceinline__ u64 mul_shoup_lazy(u64 y, ulonglong2 w, u64 Q) {
+    return w.x * y - __umul64hi(w.y, y) * Q;
+}
+
+struct U128 {
+    u64 lo, hi;
+};
+__device__ __forceinline__ void mac128(U128& a, u64 x, u64 y) {
+    const u64 lo = x * y;
+    a.lo += lo;
+    a.hi += __umul64hi(x, y) + (a.lo < lo ? 1 : 0);
+}
+__device__ __forceinline__ void add128(U128& a, u64 x) {
+    a.lo += x;
+    a.hi += (a.lo < x ? 1 : 0);
+}
+// (hi * 2^64 + lo) mod Q for hi * c64 < 2^63, c64 = 2^64 mod Q, mu64 = floor(2^64 / Q)
+__device__ __forceinline__ u64 reduce128(U128 a, u64 Q, u64 c64, u64 mu64) {
+    const u64 t = a.hi * c64;
+    u64 s = t + a.lo;
+    if (s < t) s += c64;  // wrapped once: 2^64 = c64 (mod Q); s < t < 2^63 so no second wrap
+    u64 r = s - __umul64hi(s, mu64) * Q;  // quotient estimate low by at most 2
+    r = csub(r, 2 * Q);
+    return csub(r, Q);
+}
+
+__device__ __forceinline__ u32 phys(u32 j) { return j + ((j >> 6) << 2); }
+
+template <int LOGN>
+struct Cfg {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int LE = LOGN - 6;
+    static constexpr int E = 1 << LE;
+    static constexpr int NP = N + (N >> 6) * 4;
+    static constexpr int F2LO = (6 > LE) ? 6 - LE : 0;
+    static_assert(LOGN >= 9 && LOGN <= 11, "supported ring sizes: 512, 1024, 2048");
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int LOGN, int LO>
+__device__ __forceinline__ u32 elem_j(u32 lane, int r) {
+    constexpr int LE = Cfg<LOGN>::LE;
+    return ((lane >> LO) << (LO + LE)) | ((u32)r << LO) | (lane & ((1u << LO) - 1u));
+}
+template <int LOGN, int LO>
+__device__ __forceinline__ void load_pass(const u64* poly, u32 lane, u64 (&x)[Cfg<LOGN>::E]) {
+#pragma unroll
+    for (int r = 0; r < Cfg<LOGN>::E; ++r) x[r] = poly[phys(elem_j<LOGN, LO>(lane, r))];
+}
+template <int LOGN, int LO>
+__device__ __forceinline__ void store_pass(u64* poly, u32 lane, const u64 (&x)[Cfg<LOGN>::E]) {
+#pragma unroll
+    for (int r = 0; r < Cfg<LOGN>::E; ++r) poly[phys(elem_j<LOGN, LO>(lane, r))] = x[r];
+}
+
+// forward (Cooley-Tukey) stage on index bit B, no correction: values grow by < 2Q per stage
+template <int LOGN, int LO, int B>
+__device__ __forceinline__ void fwd_stage(u64 (&x)[Cfg<LOGN>::E], u32 lane, const ulonglong2* __restrict__ tw, u64 Q) {
+    constexpr int LE = Cfg<LOGN>::LE, E = Cfg<LOGN>::E, rb = B - LO;
+    constexpr u32 m = 1u << (LOGN - 1 - B);
+    const u32 hi = (lane >> LO) << (LO + LE - B - 1);
+    const u64 Q2 = 2 * Q;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        if (r & (1 << rb)) continue;
+        const ulonglong2 w = tw[m + (hi | (u32)(r >> (rb + 1)))];
+        const u64 X = x[r];
+        const u64 T = mul_shoup_lazy(x[r | (1 << rb)], w, Q);
+        x[r] = X + T;
+        x[r | (1 << rb)] = X + Q2 - T;
+    }
+}
+// inverse (Gentleman-Sande) stage number S (0 = first): inputs < 2^(S+1) Q, the sum is left
+// uncorrected, the difference is offset by 2^(S+1) Q; inverse twiddles derived from the forward
+// table (psi^-k = -psi^(N-k), Shoup companion = bitwise complement)
+template <int LOGN, int LO, int B, int S>
+__device__ __forceinline__ void inv_stage(u64 (&x)[Cfg<LOGN>::E], u32 lane, const ulonglong2* __restrict__ tw, u64 Q) {
+    constexpr int LE = Cfg<LOGN>::LE, E = Cfg<LOGN>::E, rb = B - LO;
+    constexpr u32 m = 1u << (LOGN - 1 - B);
+    const u32 hi = (lane >> LO) << (LO + LE - B - 1);
+    const u64 off = Q << (S + 1);
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        if (r & (1 << rb)) continue;
+        const ulonglong2 f = tw[(2 * m - 1) - (hi | (u32)(r >> (rb + 1)))];
+        const ulonglong2 w = make_ulonglong2(Q - f.x, ~f.y);
+        const u64 X = x[r], Y = x[r | (1 << rb)];
+        x[r] = X + Y;
+        x[r | (1 << rb)] = mul_shoup_lazy(X + off - Y, w, Q);
+    }
+}
+template <int LOGN, int LO, int BHI, int BLO>
+__device__ __forceinline__ void fwd_stages(u64 (&x)[Cfg<LOGN>::E], u32 lane, const ulonglong2* tw, u64 Q) {
+    if constexpr (BHI >= BLO) {
+        fwd_stage<LOGN, LO, BHI>(x, lane, tw, Q);
+        fwd_stages<LOGN, LO, BHI - 1, BLO>(x, lane, tw, Q);
+    }
+}
+template <int LOGN, int LO, int BLO, int BHI>
+__device__ __forceinline__ void inv_stages(u64 (&x)[Cfg<LOGN>::E], u32 lane, const ulonglong2* tw, u64 Q) {
+    if constexpr (BLO <= BHI) {
+        inv_stage<LOGN, LO, BLO, BLO>(x, lane, tw, Q);  // stage number == bit index
+        inv_stages<LOGN, LO, BLO + 1, BHI>(x, lane, tw, Q);
+    }
+}
+
+// forward NTT by one wave in LDS; input < 2Q, output bit-reversed, < (2*LOGN+2) Q unless NORM
+template <int LOGN, bool NORM>
+__device__ __forceinline__ void ntt_forward_wave(u64* poly, const ulonglong2* tw, u32 lane, u64 Q, u64 mu64) {
+    using C = Cfg<LOGN>;
+    u64 x[C::E];
+    load_pass<LOGN, 6>(poly, lane, x);
+    fwd_stages<LOGN, 6, LOGN - 1, 6>(x, lane, tw, Q);
+    store_pass<LOGN, 6>(poly, lane, x);
+    wave_sync();
+    load_pass<LOGN, C::F2LO>(poly, lane, x);
+    fwd_stages<LOGN, C::F2LO, 5, C::F2LO>(x, lane, tw, Q);
+    if constexpr (C::F2LO > 0) {
+        store_pass<LOGN, C::F2LO>(poly, lane, x);
+        wave_sync();
+        load_pass<LOGN, 0>(poly, lane, x);
+        fwd_stages<LOGN, 0, C::F2LO - 1, 0>(x, lane, tw, Q);
+    }
+    if constexpr (NORM) {
+#pragma unroll
+        for (int r = 0; r < C::E; ++r) {
+            u64 v = x[r] - __umul64hi(x[r], mu64) * Q;
+            x[r] = csub(csub(v, 2 * Q), Q);
+        }
+    }
+    store_pass<LOGN, 0>(poly, lane, x);
+    wave_sync();
+}
+
+// inverse NTT by one wave; src bit-reversed < 2Q; coefficient j = (r << 6) | lane in x[r], in [0, Q)
+template <int LOGN>
+__device__ __forceinline__ void ntt_inverse_wave(const u64* src, u64* tmp, const ulonglong2* tw, u32 lane, u64 Q,
+                                                 ulonglong2 ninv, u64 (&x)[Cfg<LOGN>::E]) {
+    using C = Cfg<LOGN>;
+    constexpr int LE = C::LE;
+    load_pass<LOGN, 0>(src, lane, x);
+    inv_stages<LOGN, 0, 0, LE - 1>(x, lane, tw, Q);
+    store_pass<LOGN, 0>(tmp, lane, x);
+    wave_sync();
+    load_pass<LOGN, LE>(tmp, lane, x);
+    inv_stages<LOGN, LE, LE, 2 * LE - 1>(x, lane, tw, Q);
+    store_pass<LOGN, LE>(tmp, lane, x);
+    wave_sync();
+    load_pass<LOGN, 6>(tmp, lane, x);
+    inv_stages<LOGN, 6, 2 * LE, LOGN - 1>(x, lane, tw, Q);
+#pragma unroll
+    for (int r = 0; r < C::E; ++r) x[r] = csub(mul_shoup_lazy(x[r], ninv, Q), Q);
+}
+
+template <int LOGN>
+__device__ __forceinline__ u64 psi_pow(const ulonglong2* tw, u32 e, u64 Q) {
+    constexpr u32 N = 1u << LOGN;
+    const u64 v = tw[__brev(e & (N - 1)) >> (32 - LOGN)].x;
+    return (e & N) ? Q - v : v;
+}
+
+__device__ __forceinline__ u32 gate_const(u32 op, u32 q) {
+    const u32 e = q >> 3;
+    switch (op) {
+        case BCE_OR: case BCE_XOR_FAST: return 5 * e;
+        case BCE_NOR: case BCE_XNOR_FAST: return e;
+        case BCE_NAND: return 3 * e;
+        default: return 7 * e;
+    }
+}
+
+template <int LOGN, int DG, bool AP>
+__global__ __launch_bounds__(128 * DG) void k_blind_rotate64(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
+                                                              u32 slot_stride, u64* __restrict__ acc_out) {
+    using C = Cfg<LOGN>;
+    constexpr int N = C::N, NP = C::NP, E = C::E;
+    constexpr u32 R = 2 * DG, T = 64 * R;
+    extern __shared__ __align__(16) u64 smem64[];
+    u64* acc = smem64;            // [2][NP] EVALUATION domain, [0, Q)
+    u64* dct = acc + 2 * NP;      // [R][NP]
+    u32* av = reinterpret_cast<u32*>(dct + R * NP);
+    const ulonglong2* __restrict__ tw = P.tw64;
+
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 Q = P.Q64;
+    const u32 q = P.q, qm = q - 1, n = P.n;
+    const bce_gate_desc g = descs[blockIdx.x % n_desc];
+    const u32 soff = (blockIdx.x / n_desc) * slot_stride;
+    {
+        const u32* in0 = P.pool + (size_t)(g.in0 + soff) * P.pool_stride;
+        const u32* in1 = P.pool + (size_t)(g.in1 + soff) * P.pool_stride;
+        const bool two = g.op <= BCE_XNOR_FAST;
+        for (u32 i = tid; i <= n; i += T) {
+            u32 v0 = in0[i];
+            if (g.neg0) v0 = ((i == n ? (q >> 2) : 0u) - v0) & qm;
+            u32 v = v0;
+            if (two) {
+                u32 v1 = in1[i];
+                if (g.neg1) v1 = ((i == n ? (q >> 2) : 0u) - v1) & qm;
+                v = (g.op == BCE_XOR_FAST || g.op == BCE_XNOR_FAST) ? (2u * (v0 - v1)) & qm : (v0 + v1) & qm;
+            } else if (i == n) {
+                v = (v0 + (q >> 2)) & qm;
+            }
+            av[i] = v;
+        }
+    }
+    __syncthreads();
+    {
+        const u32 b = av[n];
+        const u32 q1 = gate_const(g.op, q), q2 = (q1 + (q >> 1)) & qm;
+        const u64 pos = P.Q8p1_64, neg = Q - P.Q8p1_64;
+        for (u32 j = tid; j < (u32)N; j += T) {
+            u64 v = 0;
+            if (j % P.factor == 0) {
+                u32 t = (b - j / P.factor) & qm;
+                bool in = (q1 < q2) ? (t >= q1 && t < q2) : !(t >= q2 && t < q1);
+                v = in ? neg : pos;
+            }
+            acc[phys(j)] = 0;
+            acc[NP + phys(j)] = v;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) ntt_forward_wave<LOGN, true>(acc + NP, tw, lane, Q, P.mu64);
+    __syncthreads();
+
+    const ulonglong2 ninv = make_ulonglong2(P.Ninv64, P.Ninv64_s);
+    constexpr size_t rgsw = (size_t)R * 2 * N;
+    const u64* __restrict__ bsk = P.bsk64;
+    const u32 nsteps = AP ? n * P.dR : n;
+    for (u32 step = 0; step < nsteps; ++step) {
+        u32 ap = 0;
+        const u64* bk;
+        if constexpr (!AP) {
+            ap = ((q - av[step]) & qm) * P.factor;
+            if (ap == 0) continue;
+            bk = bsk + (size_t)step * 2 * rgsw;
+        } else {
+            const u32 i = step / P.dR, k = step - i * P.dR;
+            u32 aI = (q - av[i]) & qm;
+            for (u32 t = 0; t < k; ++t) aI /= P.baseR;
+            const u32 a0 = aI % P.baseR;
+            if (a0 == 0) continue;
+            bk = bsk + (((size_t)i * P.baseR + a0) * P.dR + k) * rgsw;
+        }
+        if (wave < 2) {
+            u64 x[E];
+            ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, tw, lane, Q, ninv, x);
+            const int gsh = 64 - (int)P.gBits;
+            const u64 Qh = Q >> 1;
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                long long d = (x[r] < Qh) ? (long long)x[r] : (long long)x[r] - (long long)Q;
+                const u32 pj = phys(((u32)r << 6) | lane);
+#pragma unroll
+                for (u32 l = 0; l < (u32)DG; ++l) {
+                    long long rem = (long long)((u64)d << gsh) >> gsh;
+                    d = (d - rem) >> P.gBits;
+                    dct[(2 * l + wave) * NP + pj] = (u64)(rem + (long long)Q);  // in (Q - B/2, Q + B/2)
+                }
+            }
+        }
+        __syncthreads();
+        ntt_forward_wave<LOGN, false>(dct + wave * NP, tw, lane, Q, P.mu64);
+        __syncthreads();
+        const bool odd = ap & 1u;
+        for (u32 item = tid; item < 2u * (N / 2); item += T) {
+            const u32 c = item / (N / 2), p0 = (item % (N / 2)) * 2;
+            const u32 pp = phys(p0);
+            const u64* bp = bk + (size_t)c * N + p0;
+            U128 sp[2] = {{0, 0}, {0, 0}}, sn[2] = {{0, 0}, {0, 0}};
+#pragma unroll
+            for (u32 l = 0; l < R; ++l) {
+                const ulonglong2 d = *reinterpret_cast<const ulonglong2*>(dct + l * NP + pp);
+                const ulonglong2 kp = *reinterpret_cast<const ulonglong2*>(bp + (size_t)l * 2 * N);
+                mac128(sp[0], d.x, kp.x);
+                mac128(sp[1], d.y, kp.y);
+                if constexpr (!AP) {
+                    const ulonglong2 kn = *reinterpret_cast<const ulonglong2*>(bp + rgsw + (size_t)l * 2 * N);
+                    mac128(sn[0], d.x, kn.x);
+                    mac128(sn[1], d.y, kn.y);
+                }
+            }
+            u64 a[2];
+            if constexpr (AP) {
+                a[0] = reduce128(sp[0], Q, P.c64, P.mu64);
+                a[1] = reduce128(sp[1], Q, P.c64, P.mu64);
+            } else {
+                // positions p0, p0+1: brv(p0+1) = brv(p0) + N/2, so the monomials differ by psi^(N a') = (-1)^a'
+                const u32 k0 = __brev(p0) >> (32 - LOGN);
+                const u32 ex = ((2 * k0 + 1) * ap) & (2 * N - 1);
+                u64 mp[2], mn[2];
+                mp[0] = psi_pow<LOGN>(tw, ex, Q);
+                mn[0] = psi_pow<LOGN>(tw, (2 * N - ex) & (2 * N - 1), Q);
+                mp[1] = odd ? Q - mp[0] : mp[0];
+                mn[1] = odd ? Q - mn[0] : mn[0];
+                const ulonglong2 av2 = *reinterpret_cast<const ulonglong2*>(acc + c * NP + pp);
+                const u64 old[2] = {av2.x, av2.y};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const u64 rp = reduce128(sp[e], Q, P.c64, P.mu64), rn = reduce128(sn[e], Q, P.c64, P.mu64);
+                    U128 t = {0, 0};
+                    mac128(t, rp, mp[e] - 1);
+                    mac128(t, rn, mn[e] - 1);
+                    add128(t, old[e]);
+                    a[e] = reduce128(t, Q, P.c64, P.mu64);
+                }
+            }
+            *reinterpret_cast<ulonglong2*>(acc + c * NP + pp) = make_ulonglong2(a[0], a[1]);
+        }
+        __syncthreads();
+    }
+    if (wave < 2) {
+        u64 x[E];
+        ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, tw, lane, Q, ninv, x);
+        u64* out = acc_out + ((size_t)blockIdx.x * 2 + wave) * N;
+#pragma unroll
+        for (int r = 0; r < E; ++r) out[((u32)r << 6) | lane] = x[r];
+    }
+}
+
+// batched NTT over global memory, one wave per polynomial
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_ntt_batch64(DevParams P, u64* __restrict__ polys, u32 count, int inverse) {
+    using C = Cfg<LOGN>;
+    constexpr int N = C::N, NP = C::NP, E = C::E;
+    extern __shared__ __align__(16) u64 smem64[];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    u64* mine = smem64 + wave * NP;
+    for (u32 p = blockIdx.x * W + wave; p < count; p += gridDim.x * W) {
+        u64* gp = polys + (size_t)p * N;
+        for (int r = 0; r < E; ++r) {
+            const u32 j = ((u32)r << 6) | lane;
+            mine[phys(j)] = gp[j];
+        }
+        wave_sync();
+        if (!inverse) {
+            ntt_forward_wave<LOGN, true>(mine, P.tw64, lane, P.Q64, P.mu64);
+            for (int r = 0; r < E; ++r) {
+                const u32 j = ((u32)r << 6) | lane;
+                gp[j] = mine[phys(j)];
+            }
+        } else {
+            u64 x[E];
+            ntt_inverse_wave<LOGN>(mine, mine, P.tw64, lane, P.Q64, make_ulonglong2(P.Ninv64, P.Ninv64_s), x);
+#pragma unroll
+            for (int r = 0; r < E; ++r) gp[((u32)r << 6) | lane] = x[r];
+        }
+        wave_sync();
+    }
+}
+
+__global__ void k_pointwise_mac64(DevParams P, u64* __restrict__ b, const u64* __restrict__ a, const u64* __restrict__ z,
+                                  u32 count, u32 b_step) {
+    const size_t total = (size_t)count * P.N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const u32 k = (u32)(i & (P.N - 1));
+        const size_t bi = (i >> P.logN) * b_step * P.N + k;
+        U128 t = {0, 0};
+        mac128(t, a[i], z[k]);
+        add128(t, b[bi]);
+        b[bi] = reduce128(t, P.Q64, P.c64, P.mu64);
+    }
+}
+
+}  // namespace w64
+
+size_t blind_rotate64_lds_bytes(const DevParams& P) {
+    const size_t N = P.N, NP = N + (N >> 6) * 4, R = 2 * P.dG;
+    return (2 + R) * NP * sizeof(u64) + ((P.n + 1 + 3) & ~3u) * sizeof(u32);
+}
+
+hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
+                                 u64* acc_out, hipStream_t s) {
+    using K = void (*)(DevParams, const bce_gate_desc*, u32, u32, u64*);
+    const bool ap = P.method_ap != 0;
+    K kern = nullptr;
+    if (P.dG == 3) {
+        switch (P.logN) {
+            case 9: kern = ap ? w64::k_blind_rotate64<9, 3, true> : w64::k_blind_rotate64<9, 3, false>; break;
+            case 10: kern = ap ? w64::k_blind_rotate64<10, 3, true> : w64::k_blind_rotate64<10, 3, false>; break;
+            case 11: kern = ap ? w64::k_blind_rotate64<11, 3, true> : w64::k_blind_rotate64<11, 3, false>; break;
+            default: break;
+        }
+    } else if (P.dG == 4 && P.logN == 9) {
+        kern = ap ? w64::k_blind_rotate64<9, 4, true> : w64::k_blind_rotate64<9, 4, false>;
+    }
+    if (!kern) return hipErrorInvalidValue;
+    const size_t lds = blind_rotate64_lds_bytes(P);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(n_desc * instances), dim3(128 * P.dG), lds, s, P, d, n_desc, slot_stride, acc_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_ntt_batch64(const DevParams& P, u64* polys, u32 count, int inverse, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    const size_t N = P.N, NP = N + (N >> 6) * 4;
+    const u32 W = 4;
+    const size_t lds = W * NP * sizeof(u64);
+    u32 blocks = (count + W - 1) / W;
+    if (blocks > 4096) blocks = 4096;
+    void (*kern)(DevParams, u64*, u32, int) = nullptr;
+    switch (P.logN) {
+        case 9: kern = w64::k_ntt_batch64<9>; break;
+        case 10: kern = w64::k_ntt_batch64<10>; break;
+        case 11: kern = w64::k_ntt_batch64<11>; break;
+        default: return hipErrorInvalidValue;
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), lds, s, P, polys, count, inverse);
+    return hipGetLastError();
+}
+
+hipError_t launch_pointwise_mac64(const DevParams& P, u64* b, const u64* a, const u64* z, u32 count, u32 b_step,
+                                  hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(w64::k_pointwise_mac64, dim3(2048), dim3(256), 0, s, P, b, a, z, count, b_step);
+    return hipGetLastError();
+}
+
+}  // namespace bce

@@ -186,7 +186,7 @@ def test_errors_are_reported_not_thrown(bce):
         c.EvalGates([(bce.AND, 0, 1, 2)])
     assert e.value.code == bce.ERR_POOL
     with pytest.raises(bce.BceError) as e:
-        bce.BinFHEContext(bce.STD192, bce.GINX)   # 37-bit ring modulus needs the 64-bit kernels: not built this round
+        bce.BinFHEContext(bce.STD256, bce.GINX)   # N = 2048 with 4 gadget digits: not instantiated
     assert e.value.code == bce.ERR_UNSUPPORTED
 
 
@@ -241,3 +241,68 @@ def test_ap_std128_gate_same_seed_keys(bce, orc):
     assert np.array_equal(out[0], o.eval_bingate(bce.NAND, ca, cb))
     assert np.array_equal(out[1], o.eval_bingate(bce.OR, ca, cb))
     assert list(c.Decrypt([2, 3])) == [0, 1]
+
+
+# ---- 64-bit ring modulus (STD192: Q ~ 2^37, N = 2048): kernels64.hip -------------------------------
+def _custom64(orc):
+    L = orc.lib()
+    Q = L.bo_previous_prime(L.bo_first_prime(37, 1024), 1024)      # 37-bit prime = 1 mod 2N, N = 512
+    #       n   N    q    Q  qKS      baseKS baseG    baseR
+    return (16, 512, 512, Q, 1 << 15, 32,    1 << 13, 23)
+
+
+@pytest.mark.parametrize("method", ["GINX", "AP"])
+def test_q64_custom_context_bit_exact_stages(bce, orc, method):
+    params = _custom64(orc)
+    o = orc.Oracle(method=getattr(orc, method), custom=params)
+    o.keygen(31337)
+    c = bce.BinFHEContext(method=getattr(bce, method), custom=params)
+    assert o.params == c.params and o.params["Q"] > (1 << 36) and o.params["dG"] == 3
+    # NTT
+    rng = np.random.default_rng(3)
+    polys = rng.integers(0, o.params["Q"], size=(3, o.N), dtype=np.uint64)
+    fwd = c.debug_ntt(polys, inverse=False)
+    for k in range(3):
+        assert np.array_equal(fwd[k], o.ntt_forward(polys[k]))
+    assert np.array_equal(c.debug_ntt(fwd, inverse=True), polys)
+    # engine keygen == oracle keygen (u64 words), then gates with imported keys
+    c.KeyGen(31337)
+    assert np.array_equal(c.export_bsk(), o.bsk()) and np.array_equal(c.export_ksk(), o.ksk())
+    c.import_keys(o.sk(), o.z(), o.bsk(), o.ksk())
+    cases = _gate_cases(o, base=40)
+    nb = len(cases)
+    c.pool_reserve(3 * nb)
+    c.lwe_write(np.arange(2 * nb, dtype=np.uint32), np.concatenate([np.stack([ca, cb]) for (_, _, _, ca, cb) in cases]))
+    descs = [(g, 2 * i, 2 * i + 1, 2 * nb + i) for i, (g, _, _, _, _) in enumerate(cases)]
+    acc, lweN, ks = c.debug_eval_stages(descs)
+    out = c.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32))
+    for i, (g, a, b, ca, cb) in enumerate(cases):
+        r_acc = o.blind_rotate(g, o.gate_prep(g, ca, cb))
+        assert np.array_equal(acc[i], r_acc), "64-bit accumulator differs, case %d" % i
+        r_lweN = o.extract_modswitch(r_acc)
+        assert np.array_equal(lweN[i], r_lweN)
+        r_ks = o.keyswitch(r_lweN)
+        assert np.array_equal(ks[i], r_ks)
+        assert np.array_equal(out[i], o.modswitch_final(r_ks))
+        assert o.decrypt(out[i]) == _truth(g, a, b)
+
+
+@pytest.mark.parametrize("method", ["GINX", "AP"])
+def test_std192_gate_same_seed_keys(bce, orc, method):
+    """BASELINE config 5 parameter set (STD192: n=1024, N=2048, Q=137438822401, qKS=2^19; AP key = 12.9 GB).
+    Keys are derived from the same seed on both sides (keygen parity is established above)."""
+    o = orc.Oracle(orc.STD192, getattr(orc, method))
+    o.keygen(2718)
+    c = bce.BinFHEContext(bce.STD192, getattr(bce, method))
+    c.KeyGen(2718)
+    assert o.params == c.params
+    ca, cb = o.encrypt(1, 0), o.encrypt(0, 1)
+    c.pool_reserve(4)
+    c.lwe_write([0, 1], np.stack([ca, cb]))
+    c.EvalGates([(bce.AND, 0, 1, 2), (bce.OR, 0, 1, 3)])
+    out = c.lwe_read([2, 3])
+    assert np.array_equal(out[0], o.eval_bingate(bce.AND, ca, cb))
+    assert np.array_equal(out[1], o.eval_bingate(bce.OR, ca, cb))
+    assert list(c.Decrypt([2, 3])) == [0, 1]
+    o.close()
+    c.close()
