@@ -183,11 +183,13 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         const bool ok2 = sum < ((u128)1 << 64);
         const u128 folded = (sum >> 32) * P.c32 + ((u128)1 << 32);
         const bool ok3 = folded < ((u128)1 << (32 + P.red_shift));
-        P.lazy = (ok1 && ok2 && ok3) ? 1 : 0;
+        // (4) MAC keeps rp, rn < 3Q and acc < 2Q: 3Q*Q + 3Q*Q + 2Q below the Barrett bound, 3Q < 2^32
+        const bool ok4 = (u128)6 * Q * Q + 2 * Q < ((u128)1 << (32 + P.red_shift)) && (u128)3 * Q < ((u128)1 << 32);
+        P.lazy = (ok1 && ok2 && ok3 && ok4) ? 1 : 0;
     }
     {
         const char* occ = std::getenv("BCE_OCCUPANCY");  // development knob: 2 or 3 workgroups per CU
-        P.occupancy_target = (occ && occ[0] == '2') ? 2 : 3;
+        P.occupancy_target = (occ && occ[0] == '3') ? 3 : 2;
         const size_t lds = (2 * (size_t)N + (2 + 2 * c->dG) * ((size_t)N + (N >> 6) * 4) + ((n + 1 + 3) & ~3u)) * 4;
         if (3 * lds > 160 * 1024) P.occupancy_target = 2;
     }

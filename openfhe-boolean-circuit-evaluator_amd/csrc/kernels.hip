@@ -35,6 +35,37 @@ __device__ __forceinline__ u32 mul_shoup_lazy(u32 y, uint2 w, u32 Q) {
     return w.x * y - qh * Q;
 }
 
+// ---- register-pair helpers for the 5-instruction lazy butterfly -------------------------------
+// v_mad_u64_u32 is full rate on gfx950 (same issue cost as v_mul_lo_u32, measured), so using its LOW
+// word gives multiply+add in one instruction.  Its addend and result are 64-bit register pairs; NTT
+// elements are therefore carried as pairs whose high half is a don't-care, which costs registers
+// but no instructions.
+__device__ __forceinline__ u64 mad64(u32 a, u32 b, u64 c) {
+    u64 r, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// a*b as a register pair (addend = inline constant 0)
+__device__ __forceinline__ u64 mul64(u32 a, u32 b) {
+    u64 r, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(carry) : "v"(a), "v"(b));
+    return r;
+}
+// y * w mod Q lazily in [0, 2Q) with 3 instructions: v_mul_hi_u32 + 2 x v_mad_u64_u32 (low word)
+__device__ __forceinline__ u32 mul_shoup_lazy3(u32 y, uint2 w, u32 Q) {
+    return (u32)mad64(__umulhi(w.y, y), 0u - Q, mul64(y, w.x));
+}
+__device__ __forceinline__ u64 pair_of(u32 lo) {
+    u32 junk = __builtin_nondeterministic_value(junk);
+    return ((u64)junk << 32) | lo;
+}
+__device__ __forceinline__ u64 with_lo(u64 pair, u32 lo) { return (pair & 0xFFFFFFFF00000000ull) | lo; }
+
+// x < 2^(32+shift) -> value congruent to x mod Q in [0, 3Q): shift, mulhi, one low-word mad
+__device__ __forceinline__ u32 barrett_lazy3(u64 x, u32 Q, u32 shift, u32 mu) {
+    return (u32)mad64(__umulhi((u32)(x >> shift), mu), 0u - Q, x);
+}
+
 // x < 2^(2*bitlen(Q)+3) -> x mod Q in [0, Q)
 __device__ __forceinline__ u32 barrett_reduce(u64 x, u32 Q, u32 shift, u32 mu) {
     u32 x1 = (u32)(x >> shift);
@@ -130,6 +161,43 @@ __device__ __forceinline__ void fwd_stage(u32 (&x)[Cfg<LOGN>::E], u32 lane, cons
     }
 }
 
+// Lazy Cooley-Tukey stage on register pairs: X' = lo(mad(floor(Y*w'/2^32), -Q, mad(Y, w, X))),
+// Y' = 2X + 2Q - X'  ->  v_mul_hi_u32, 2 x v_mad_u64_u32, v_lshl_add_u32, v_sub_u32.
+template <int LOGN, int LO, int B>
+__device__ __forceinline__ void fwd_stage_pair(u64 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q) {
+    constexpr int LE = Cfg<LOGN>::LE, E = Cfg<LOGN>::E;
+    constexpr int rb = B - LO;
+    constexpr u32 m = 1u << (LOGN - 1 - B);
+    const u32 hi = (lane >> LO) << (LO + LE - B - 1);
+    const u32 Q2 = 2 * Q, negQ = 0u - Q;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        if (r & (1 << rb)) continue;
+        const uint2 w = tw[m + (hi | (u32)(r >> (rb + 1)))];
+        const u32 X = (u32)x[r], Y = (u32)x[r | (1 << rb)];
+        const u64 t = mad64(__umulhi(Y, w.y), negQ, mad64(Y, w.x, x[r]));
+        x[r | (1 << rb)] = with_lo(x[r | (1 << rb)], (X << 1) + Q2 - (u32)t);
+        x[r] = t;
+    }
+}
+template <int LOGN, int LO, int BHI, int BLO>
+__device__ __forceinline__ void fwd_stages_pair(u64 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q) {
+    if constexpr (BHI >= BLO) {
+        fwd_stage_pair<LOGN, LO, BHI>(x, lane, tw, Q);
+        fwd_stages_pair<LOGN, LO, BHI - 1, BLO>(x, lane, tw, Q);
+    }
+}
+template <int LOGN, int LO>
+__device__ __forceinline__ void load_pass_pair(const u32* poly, u32 lane, u64 (&x)[Cfg<LOGN>::E]) {
+#pragma unroll
+    for (int r = 0; r < Cfg<LOGN>::E; ++r) x[r] = pair_of(poly[phys(elem_j<LOGN, LO>(lane, r))]);
+}
+template <int LOGN, int LO>
+__device__ __forceinline__ void store_pass_pair(u32* poly, u32 lane, const u64 (&x)[Cfg<LOGN>::E]) {
+#pragma unroll
+    for (int r = 0; r < Cfg<LOGN>::E; ++r) poly[phys(elem_j<LOGN, LO>(lane, r))] = (u32)x[r];
+}
+
 // Gentleman-Sande stage on bit B; values stay in [0, 2Q).  Inverse twiddles come from the
 // FORWARD table: psi^-k = -psi^(N-k), i.e. itw[m+i] = Q - tw[m + (m-1-i)], and the Shoup
 // companion of Q - w is the bitwise complement of w's (Q is prime, so w*2^32/Q is never integral).
@@ -147,7 +215,7 @@ __device__ __forceinline__ void inv_stage(u32 (&x)[Cfg<LOGN>::E], u32 lane, cons
         const uint2 w = make_uint2(Q - f.x, ~f.y);
         u32 X = x[r], Y = x[r | (1 << rb)];
         x[r] = csub(X + Y, Q2);
-        x[r | (1 << rb)] = mul_shoup_lazy(X + Q2 - Y, w, Q);
+        x[r | (1 << rb)] = mul_shoup_lazy3(X + Q2 - Y, w, Q);
     }
 }
 
@@ -174,17 +242,32 @@ template <int LOGN, bool LAZY, bool NORM = true>
 __device__ __forceinline__ void ntt_forward_wave(u32* poly, const uint2* twf, u32 lane, u32 Q, u32 mu32) {
     using C = Cfg<LOGN>;
     u32 x[C::E];
-    load_pass<LOGN, 6>(poly, lane, x);
-    fwd_stages<LOGN, 6, LOGN - 1, 6, LAZY>(x, lane, twf, Q);
-    store_pass<LOGN, 6>(poly, lane, x);
-    wave_sync();
-    load_pass<LOGN, C::F2LO>(poly, lane, x);
-    fwd_stages<LOGN, C::F2LO, 5, C::F2LO, LAZY>(x, lane, twf, Q);
-    if constexpr (C::F2LO > 0) {
-        store_pass<LOGN, C::F2LO>(poly, lane, x);
+    if constexpr (LAZY && C::F2LO > 0) {
+        // passes 1 and 2 on register pairs (5-instruction butterflies), pass 3 on plain registers
+        u64 xp[C::E];
+        load_pass_pair<LOGN, 6>(poly, lane, xp);
+        fwd_stages_pair<LOGN, 6, LOGN - 1, 6>(xp, lane, twf, Q);
+        store_pass_pair<LOGN, 6>(poly, lane, xp);
+        wave_sync();
+        load_pass_pair<LOGN, C::F2LO>(poly, lane, xp);
+        fwd_stages_pair<LOGN, C::F2LO, 5, C::F2LO>(xp, lane, twf, Q);
+        store_pass_pair<LOGN, C::F2LO>(poly, lane, xp);
         wave_sync();
         load_pass<LOGN, 0>(poly, lane, x);
         fwd_stages<LOGN, 0, C::F2LO - 1, 0, LAZY>(x, lane, twf, Q);
+    } else {
+        load_pass<LOGN, 6>(poly, lane, x);
+        fwd_stages<LOGN, 6, LOGN - 1, 6, LAZY>(x, lane, twf, Q);
+        store_pass<LOGN, 6>(poly, lane, x);
+        wave_sync();
+        load_pass<LOGN, C::F2LO>(poly, lane, x);
+        fwd_stages<LOGN, C::F2LO, 5, C::F2LO, LAZY>(x, lane, twf, Q);
+        if constexpr (C::F2LO > 0) {
+            store_pass<LOGN, C::F2LO>(poly, lane, x);
+            wave_sync();
+            load_pass<LOGN, 0>(poly, lane, x);
+            fwd_stages<LOGN, 0, C::F2LO - 1, 0, LAZY>(x, lane, twf, Q);
+        }
     }
     if constexpr (NORM || !LAZY) {
 #pragma unroll
@@ -220,7 +303,7 @@ __device__ __forceinline__ void ntt_inverse_wave(const u32* src, u32* tmp, const
     load_pass<LOGN, 6>(tmp, lane, x);
     inv_stages<LOGN, 6, 2 * LE, LOGN - 1>(x, lane, twi, Q);
 #pragma unroll
-    for (int r = 0; r < C::E; ++r) x[r] = csub(mul_shoup_lazy(x[r], ninv, Q), Q);
+    for (int r = 0; r < C::E; ++r) x[r] = csub(mul_shoup_lazy3(x[r], ninv, Q), Q);
 }
 
 // psi^e for e in [0, 2N) from the forward table (tw_f[brv(i)] = psi^i, psi^(i+N) = -psi^i)
@@ -229,6 +312,13 @@ __device__ __forceinline__ u32 psi_pow(const uint2* twf, u32 e, u32 Q) {
     constexpr u32 N = 1u << LOGN;
     u32 v = twf[__brev(e & (N - 1)) >> (32 - LOGN)].x;
     return (e & N) ? Q - v : v;
+}
+
+// one 16-byte BSK fragment: voff = per-thread byte offset, soff = wave-uniform row byte offset
+__device__ __forceinline__ uint4 bsk_row(__amdgpu_buffer_rsrc_t rsrc, u32 voff, u32 soff) {
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 // gate constant q1 of BootstrapGateCore (OR 5q/8, AND 7q/8, NOR q/8, NAND 3q/8)
@@ -258,7 +348,7 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
     constexpr u32 T = 64 * R;
     extern __shared__ __align__(16) u32 smem[];
     uint2* twf = reinterpret_cast<uint2*>(smem);
-    u32* acc = reinterpret_cast<u32*>(twf + N);  // [2][NP]  EVALUATION domain, [0,Q)
+    u32* acc = reinterpret_cast<u32*>(twf + N);  // [2][NP]  EVALUATION domain, [0,Q) ([0,2Q) when LAZY)
     u32* dct = acc + 2 * NP;                     // [R][NP]
     u32* av = dct + R * NP;                      // ctprep: a[0..n), b
 
@@ -310,15 +400,19 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
 
     const uint2 ninv = make_uint2(P.Ninv, P.Ninv_s);
     constexpr u32 rgsw = R * 2 * N;  // words per RGSW ciphertext
+    // GINX key = n * 2 * rgsw words < 4 GiB: one buffer resource covers it (raw, no stride, bounds-checked)
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(P.bsk), 0, AP ? 0x7FFFFFFF : (int)(n * 2 * rgsw * 4), 0x00020000);
     // GINX: one step per LWE coefficient; AP: one step per (coefficient, base-baseR digit)
     const u32 nsteps = AP ? n * P.dR : n;
     for (u32 step = 0; step < nsteps; ++step) {
-        u32 ap = 0;
+        u32 ap = 0, rowb = 0;
         const u32* bk;
         if constexpr (!AP) {
             ap = ((q - av[step]) & qm) * P.factor;  // exponent of the monomial, in [0, 2N)
             if (ap == 0) continue;                   // X^0 - 1 = 0: AddToAcc adds nothing
             bk = P.bsk + (size_t)step * 2 * rgsw;
+            rowb = step * (2 * rgsw * 4);
         } else {
             const u32 i = step / P.dR, k = step - i * P.dR;
             u32 aI = (q - av[i]) & qm;
@@ -331,7 +425,6 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
         if (wave < 2) {
             u32 x[E];
             ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, twf, lane, Q, ninv, x);
-            const int gsh = 32 - (int)P.gBits;
             const u32 Qh = Q >> 1;
 #pragma unroll
             for (int r = 0; r < E; ++r) {
@@ -339,7 +432,7 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
                 const u32 pj = phys(((u32)r << 6) | lane);
 #pragma unroll
                 for (u32 l = 0; l < (u32)DG; ++l) {
-                    int rem = (int)((u32)d << gsh) >> gsh;  // signed digit in [-B/2, B/2)
+                    int rem = __builtin_amdgcn_sbfe(d, 0, P.gBits);  // signed digit in [-B/2, B/2): v_bfe_i32
                     d = (d - rem) >> P.gBits;
                     // LAZY: rem + Q (in (Q-B/2, Q+B/2)) is as good an input as rem mod Q for the lazy NTT
                     dct[(2 * l + wave) * NP + pj] = LAZY ? (u32)(rem + (int)Q) : (rem < 0 ? (u32)(rem + (int)Q) : (u32)rem);
@@ -384,15 +477,17 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
         for (u32 item = tid; item < 2u * (N / 4); item += T) {
             const u32 c = item / (N / 4), p0 = (item % (N / 4)) * 4;
             const u32 pp = phys(p0);
-            const u32* bp = bk + (size_t)c * N + p0;
+            // buffer loads: SGPR resource over the whole key, per-row byte offset in an SGPR (SALU
+            // arithmetic), ONE 32-bit per-thread offset -> no 64-bit VALU address math for the 16 rows
+            const u32 toff = (c * N + p0) * 4u;
             // BSK rows: key+ (R loads) and the first half of key- in flight together; the second
             // half of key- reuses key+'s registers once those are consumed (bounds VGPR pressure)
             constexpr u32 H = R / 2;
             uint4 kA[R], kB[H];
 #pragma unroll
-            for (u32 l = 0; l < R; ++l) kA[l] = *reinterpret_cast<const uint4*>(bp + (size_t)l * 2 * N);
+            for (u32 l = 0; l < R; ++l) kA[l] = bsk_row(rsrc, toff, rowb + l * (2 * N * 4));
 #pragma unroll
-            for (u32 l = 0; l < H; ++l) kB[l] = *reinterpret_cast<const uint4*>(bp + rgsw + (size_t)l * 2 * N);
+            for (u32 l = 0; l < H; ++l) kB[l] = bsk_row(rsrc, toff, rowb + (rgsw + l * 2 * N) * 4);
             __builtin_amdgcn_sched_barrier(0);
             u64 sp[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -402,7 +497,7 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (u32 l = 0; l < H; ++l) kA[l] = *reinterpret_cast<const uint4*>(bp + rgsw + (size_t)(H + l) * 2 * N);
+            for (u32 l = 0; l < H; ++l) kA[l] = bsk_row(rsrc, toff, rowb + (rgsw + (H + l) * 2 * N) * 4);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (u32 l = 0; l < H; ++l) {
@@ -430,9 +525,17 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
             u32 a[4] = {a4v.x, a4v.y, a4v.z, a4v.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const u32 rp = LAZY ? barrett_fold(sp[e], P.c32, Q, P.red_shift, P.red_mu) : barrett_reduce(sp[e], Q, P.red_shift, P.red_mu);
-                const u32 rn = LAZY ? barrett_fold(sn[e], P.c32, Q, P.red_shift, P.red_mu) : barrett_reduce(sn[e], Q, P.red_shift, P.red_mu);
-                a[e] = barrett_reduce((u64)rp * (mp[e] - 1) + (u64)rn * (mn[e] - 1) + a[e], Q, P.red_shift, P.red_mu);
+                if constexpr (LAZY) {
+                    // fold the high word (sum < 2^62), reduce lazily to [0,3Q); the three-term sum
+                    // 3Q*Q + 3Q*Q + 2Q stays below the 2^(32+shift) Barrett bound; acc is kept in [0,2Q)
+                    const u32 rp = barrett_lazy3((u64)(u32)(sp[e] >> 32) * P.c32 + (u32)sp[e], Q, P.red_shift, P.red_mu);
+                    const u32 rn = barrett_lazy3((u64)(u32)(sn[e] >> 32) * P.c32 + (u32)sn[e], Q, P.red_shift, P.red_mu);
+                    a[e] = csub(barrett_lazy3((u64)rp * (mp[e] - 1) + (u64)rn * (mn[e] - 1) + a[e], Q, P.red_shift, P.red_mu), 2 * Q);
+                } else {
+                    const u32 rp = barrett_reduce(sp[e], Q, P.red_shift, P.red_mu);
+                    const u32 rn = barrett_reduce(sn[e], Q, P.red_shift, P.red_mu);
+                    a[e] = barrett_reduce((u64)rp * (mp[e] - 1) + (u64)rn * (mn[e] - 1) + a[e], Q, P.red_shift, P.red_mu);
+                }
             }
             *reinterpret_cast<uint4*>(acc + c * NP + pp) = make_uint4(a[0], a[1], a[2], a[3]);
         }
