@@ -60,6 +60,7 @@ struct bce_ctx {
     DevParams P{};
     // device tables / keys
     uint2* d_twf = nullptr;
+    u32* d_psi = nullptr;
     void* d_bsk = nullptr;       // u32 words (Q < 2^28) or u64 words (is64)
     ulonglong2* d_tw64 = nullptr;
     bool is64 = false;
@@ -143,10 +144,18 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
 
     // twiddle tables, OpenFHE ordering: tw[brv(i)] = psi^i
     std::vector<uint2> twf(N);
+    std::vector<u32> psitab(N);
     u64 p = 1;
     for (u32 i = 0; i < N; ++i) {
+        psitab[i] = c->is64 ? 0 : (u32)p;
         u32 r = bit_reverse(i, (int)c->logN);
-        twf[r] = c->is64 ? make_uint2(0, 0) : make_uint2((u32)p, (u32)(((u128)p << 32) / Q));
+        // device layout: blocks m >= 64 transposed to [slot][lane] (kernels.hip tw_pos)
+        u32 pos = r;
+        if (r >= 64) {
+            const u32 s = 31u - (u32)__builtin_clz(r), sh = s - 6, ii = r - (1u << s);
+            pos = (1u << s) + ((ii & ((1u << sh) - 1u)) << 6) + (ii >> sh);
+        }
+        twf[pos] = c->is64 ? make_uint2(0, 0) : make_uint2((u32)p, (u32)(((u128)p << 32) / Q));
         p = mul_mod(p, c->psi, Q);
     }
     if (hipMalloc(&c->d_twf, sizeof(uint2) * N) != hipSuccess) {
@@ -154,6 +163,8 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         return BCE_ERR_HIP;
     }
     hipMemcpy(c->d_twf, twf.data(), sizeof(uint2) * N, hipMemcpyHostToDevice);
+    if (hipMalloc(&c->d_psi, sizeof(u32) * N) != hipSuccess) { g_create_error = "hipMalloc(psi table) failed"; return BCE_ERR_HIP; }
+    hipMemcpy(c->d_psi, psitab.data(), sizeof(u32) * N, hipMemcpyHostToDevice);
     for (int i = 0; i < bce_ctx::kRing; ++i) hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming);
 
     DevParams& P = c->P;
@@ -202,6 +213,7 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         }
     }
     P.tw_f = c->d_twf;
+    P.psi_tab = c->d_psi;
     P.is64 = c->is64 ? 1 : 0;
     P.Q64 = Q;
     P.Q8p1_64 = Q / 8 + 1;
@@ -535,7 +547,7 @@ void bce_ctx_destroy(bce_ctx* c) {
         if (c->h_descs[i]) hipHostFree(c->h_descs[i]);
         if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
     }
-    hipFree(c->d_twf); hipFree(c->d_tw64); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc);
+    hipFree(c->d_twf); hipFree(c->d_psi); hipFree(c->d_tw64); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }

@@ -95,6 +95,21 @@ struct Cfg {
     static_assert(LOGN >= 9 && LOGN <= 11, "supported ring sizes: 512, 1024, 2048");
 };
 
+// Twiddle table layout.  Natural index m + i (m = 2^s the Cooley-Tukey block, i < m) holds
+// psi^brv(m+i).  Blocks with m >= 64 are read by the passes whose registers hold the low index
+// bits: lane L needs entries i = (L << sh) | t (sh = s - 6), a stride-2^sh pattern that is a
+// 2^sh-way LDS bank conflict.  Those blocks are therefore stored TRANSPOSED: entry (L, t) at
+// m + t*64 + L, so that a wave reads 64 consecutive uint2.  (The host builds the same layout.)
+template <u32 M>
+__device__ __forceinline__ u32 tw_pos(u32 i) {
+    if constexpr (M < 64) {
+        return M + i;
+    } else {
+        constexpr u32 sh = __builtin_ctz(M) - 6;
+        return M + ((i & ((1u << sh) - 1u)) << 6) + (i >> sh);
+    }
+}
+
 __device__ __forceinline__ void wave_sync() {
     // LDS operations of one wave execute in order; this only pins the compiler.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -153,7 +168,7 @@ __device__ __forceinline__ void fwd_stage(u32 (&x)[Cfg<LOGN>::E], u32 lane, cons
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         if (r & (1 << rb)) continue;
-        uint2 w = tw[m + (hi | (u32)(r >> (rb + 1)))];
+        uint2 w = tw[tw_pos<m>(hi | (u32)(r >> (rb + 1)))];
         u32 X = LAZY ? x[r] : csub(x[r], Q2);
         u32 T = mul_shoup_lazy(x[r | (1 << rb)], w, Q);
         x[r] = X + T;
@@ -173,7 +188,7 @@ __device__ __forceinline__ void fwd_stage_pair(u64 (&x)[Cfg<LOGN>::E], u32 lane,
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         if (r & (1 << rb)) continue;
-        const uint2 w = tw[m + (hi | (u32)(r >> (rb + 1)))];
+        const uint2 w = tw[tw_pos<m>(hi | (u32)(r >> (rb + 1)))];
         const u32 X = (u32)x[r], Y = (u32)x[r | (1 << rb)];
         const u64 t = mad64(__umulhi(Y, w.y), negQ, mad64(Y, w.x, x[r]));
         x[r | (1 << rb)] = with_lo(x[r | (1 << rb)], (X << 1) + Q2 - (u32)t);
@@ -211,7 +226,7 @@ __device__ __forceinline__ void inv_stage(u32 (&x)[Cfg<LOGN>::E], u32 lane, cons
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         if (r & (1 << rb)) continue;
-        const uint2 f = tw[(2 * m - 1) - (hi | (u32)(r >> (rb + 1)))];
+        const uint2 f = tw[tw_pos<m>((m - 1) - (hi | (u32)(r >> (rb + 1))))];
         const uint2 w = make_uint2(Q - f.x, ~f.y);
         u32 X = x[r], Y = x[r | (1 << rb)];
         x[r] = csub(X + Y, Q2);
@@ -307,10 +322,12 @@ __device__ __forceinline__ void ntt_inverse_wave(const u32* src, u32* tmp, const
 }
 
 // psi^e for e in [0, 2N) from the forward table (tw_f[brv(i)] = psi^i, psi^(i+N) = -psi^i)
+// psi^e for e in [0, 2N) from the natural-order power table psi_tab[0..N) (psi^(e+N) = -psi^e),
+// read through an SGPR buffer resource: one VALU op for the byte offset, no LDS, no bit reversal
 template <int LOGN>
-__device__ __forceinline__ u32 psi_pow(const uint2* twf, u32 e, u32 Q) {
+__device__ __forceinline__ u32 psi_pow(__amdgpu_buffer_rsrc_t psi_rsrc, u32 e, u32 Q) {
     constexpr u32 N = 1u << LOGN;
-    u32 v = twf[__brev(e & (N - 1)) >> (32 - LOGN)].x;
+    const u32 v = __builtin_amdgcn_raw_buffer_load_b32(psi_rsrc, (e & (N - 1)) << 2, 0, 0);
     return (e & N) ? Q - v : v;
 }
 
@@ -403,6 +420,7 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
     // GINX key = n * 2 * rgsw words < 4 GiB: one buffer resource covers it (raw, no stride, bounds-checked)
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(P.bsk), 0, AP ? 0x7FFFFFFF : (int)(n * 2 * rgsw * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t psi_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(P.psi_tab), 0, N * 4, 0x00020000);
     // GINX: one step per LWE coefficient; AP: one step per (coefficient, base-baseR digit)
     const u32 nsteps = AP ? n * P.dR : n;
     for (u32 step = 0; step < nsteps; ++step) {
@@ -513,8 +531,8 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
             const u32 k0 = __brev(p0) >> (32 - LOGN);
             const u32 ex = ((2 * k0 + 1) * ap) & (2 * N - 1);
             u32 mp[4], mn[4];
-            mp[0] = psi_pow<LOGN>(twf, ex, Q);
-            mn[0] = psi_pow<LOGN>(twf, (2 * N - ex) & (2 * N - 1), Q);
+            mp[0] = psi_pow<LOGN>(psi_rsrc, ex, Q);
+            mn[0] = psi_pow<LOGN>(psi_rsrc, (2 * N - ex) & (2 * N - 1), Q);
             mp[2] = csub(mul_shoup_lazy(mp[0], Ia, Q), Q);
             mn[2] = csub(mul_shoup_lazy(mn[0], Ina, Q), Q);
             mp[1] = odd ? Q - mp[0] : mp[0];

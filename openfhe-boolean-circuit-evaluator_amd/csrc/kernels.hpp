@@ -35,6 +35,7 @@ struct DevParams {
     u32 I4[4], I4s[4];     // powers of I = psi^(N/2) (primitive 4th root of unity) and Shoup companions
     const uint2* tw_f;  // [N] (psi^brv(i), shoup), index m+i as in the CT forward NTT; the inverse
                         // transform derives psi^-k = -psi^(N-k) from the same table
+    const u32* psi_tab; // [N] psi^e in natural exponent order (monomial lookups of the GINX MAC)
     const u32* bsk;     // EVALUATION domain, GINX [n][2][R][2][N]; AP [n][baseR][dR][R][2][N]
     // ---- 64-bit ring modulus path (kernels64.hip), used when is64 != 0 (Q >= 2^28) ----
     u32 is64;
