@@ -154,3 +154,22 @@ def test_aes_expanded_std128_full_circuit(bce, std_cc):
     for k, v in enumerate(vecs):
         assert c.Outputs(k)[0] == kat.aes_case(v)[1]
     assert c.stats()["bootstraps"] == 66415 * len(vecs)
+
+
+def test_sha256_new_format_std128_four_vectors_in_lock_step(bce, std_cc):
+    """BASELINE config 4: new-format sha256 (135,073 gates, 354,505 bootstraps, 5,332 levels), the four
+    reference vectors of sha-256-test.txt evaluated as K = 4 lock-step instances (1.4 M bootstraps)."""
+    c = bce.Circuit(std_cc)
+    c.ReadBristol(os.path.join(CIRCUITS, "sha256_new.txt"), new_flag=True)
+    vecs = kat.hash_vectors("sha-256-test.txt")
+    c.setInstances(len(vecs))
+    c.Reset()
+    c.setEncrypted(True)
+    for k, (inhex, outhex) in enumerate(vecs):
+        c.SetInput(kat.sha256_new_case(inhex, outhex)[0], instance=k)
+    c.Clock()
+    for k, (inhex, outhex) in enumerate(vecs):
+        assert c.Outputs(k)[0] == kat.sha256_new_case(inhex, outhex)[1], "sha-256 vector %d" % k
+    st = c.stats()
+    assert st["bootstraps"] == 354505 * len(vecs)
+    print("sha256 x%d: %.1f s, %.0f bootstraps/s" % (len(vecs), st["total_ms"] / 1e3, st["bootstraps"] / st["total_ms"] * 1e3))
