@@ -200,7 +200,7 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     }
     {
         const char* occ = std::getenv("BCE_OCCUPANCY");  // development knob: 2 or 3 workgroups per CU
-        P.occupancy_target = (occ && occ[0] == '3') ? 3 : 2;
+        P.occupancy_target = (occ && occ[0] == '2') ? 2 : 3;
         const size_t lds = (2 * (size_t)N + (2 + 2 * c->dG) * ((size_t)N + (N >> 6) * 4) + ((n + 1 + 3) & ~3u)) * 4;
         if (3 * lds > 160 * 1024) P.occupancy_target = 2;
     }

@@ -498,16 +498,35 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
             // buffer loads: SGPR resource over the whole key, per-row byte offset in an SGPR (SALU
             // arithmetic), ONE 32-bit per-thread offset -> no 64-bit VALU address math for the 16 rows
             const u32 toff = (c * N + p0) * 4u;
+            u64 sp[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0};
+            constexpr u32 H = R / 2;
+            if constexpr (OCC >= 3) {
+                // 80-VGPR budget (3 workgroups per CU): half of each key's rows in flight at a time
+#pragma unroll
+                for (u32 h = 0; h < 2; ++h) {
+                    uint4 kA[H], kB[H];
+#pragma unroll
+                    for (u32 l = 0; l < H; ++l) kA[l] = bsk_row(rsrc, toff, rowb + (h * H + l) * (2 * N * 4));
+#pragma unroll
+                    for (u32 l = 0; l < H; ++l) kB[l] = bsk_row(rsrc, toff, rowb + (rgsw + (h * H + l) * 2 * N) * 4);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (u32 l = 0; l < H; ++l) {
+                        const uint4 d = *reinterpret_cast<const uint4*>(dct + (h * H + l) * NP + pp);
+                        sp[0] += (u64)d.x * kA[l].x; sp[1] += (u64)d.y * kA[l].y; sp[2] += (u64)d.z * kA[l].z; sp[3] += (u64)d.w * kA[l].w;
+                        sn[0] += (u64)d.x * kB[l].x; sn[1] += (u64)d.y * kB[l].y; sn[2] += (u64)d.z * kB[l].z; sn[3] += (u64)d.w * kB[l].w;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
             // BSK rows: key+ (R loads) and the first half of key- in flight together; the second
             // half of key- reuses key+'s registers once those are consumed (bounds VGPR pressure)
-            constexpr u32 H = R / 2;
             uint4 kA[R], kB[H];
 #pragma unroll
             for (u32 l = 0; l < R; ++l) kA[l] = bsk_row(rsrc, toff, rowb + l * (2 * N * 4));
 #pragma unroll
             for (u32 l = 0; l < H; ++l) kB[l] = bsk_row(rsrc, toff, rowb + (rgsw + l * 2 * N) * 4);
             __builtin_amdgcn_sched_barrier(0);
-            u64 sp[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0};
 #pragma unroll
             for (u32 l = 0; l < R; ++l) {
                 const uint4 d = *reinterpret_cast<const uint4*>(dct + l * NP + pp);
@@ -526,6 +545,7 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
             for (u32 l = 0; l < H; ++l) {
                 const uint4 d = *reinterpret_cast<const uint4*>(dct + (H + l) * NP + pp);
                 sn[0] += (u64)d.x * kA[l].x; sn[1] += (u64)d.y * kA[l].y; sn[2] += (u64)d.z * kA[l].z; sn[3] += (u64)d.w * kA[l].w;
+            }
             }
             // monomials psi^(+-(2k+1)a') - 1 at the four positions
             const u32 k0 = __brev(p0) >> (32 - LOGN);
