@@ -370,7 +370,8 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
     u32* av = dct + R * NP;                      // ctprep: a[0..n), b
 
     const u32 tid = threadIdx.x;
-    const u32 lane = tid & 63, wave = tid >> 6;
+    const u32 lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keep it (and wave*NP) in SGPRs
     const u32 Q = P.Q, q = P.q, qm = q - 1, n = P.n;
 
     const bce_gate_desc g = descs[blockIdx.x % n_desc];
