@@ -193,6 +193,8 @@ def main():
         pass
     if rank == 0:
         bpb = cc.bytes_per_bootstrap()
+        pr = cc.params
+        bsk_once = 4 * pr["n"] * 2 * (2 * pr["dG"]) * 2 * pr["N"]   # u32 GINX key, read once if perfectly shared
         br_s = tm["blind_rotate_ms"] / 1e3
         achieved = (bpb * my_boot / br_s) / 1e9 if br_s > 0 else 0.0
         out = {
@@ -225,12 +227,16 @@ def main():
                 "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json)",
                 "algorithmic_bytes_per_launch": bpb * my_boot / max(1, tm["blind_rotate_launches"]),
                 "bytes_per_bootstrap": bpb,
+                # when the key is reused from cache across a batch, also state the compulsory
+                # bytes of a launch: the key once + per-bootstrap key-switch rows and ciphertext I/O
+                "compulsory_bytes_per_launch": bsk_once + (bpb - bsk_once) * my_boot / max(1, tm["blind_rotate_launches"]),
                 "avg_launch_ms": tm["blind_rotate_ms"] / max(1, tm["blind_rotate_launches"]),
                 "launches": tm["blind_rotate_launches"],
                 "tail_kernel_ms_total": tm["tail_ms"],
                 "note": "achieved = algorithmic bytes (u32 BSK + u16 KSK rows + u32 cts per bootstrap) x bootstraps / "
                         "blind-rotation kernel time from HIP events on the engine stream; the 62.8 MiB BSK is mostly served "
-                        "from L2 / Infinity Cache (traffic << algorithmic), the kernel is integer-VALU bound (84% VALU busy)",
+                        "from L2 / Infinity Cache (traffic << algorithmic), so frac can approach or exceed 1; the kernel is "
+                        "integer-VALU bound (81% VALU busy, 3.70 M wave-instructions per bootstrap, profiles/r01_final_pmc_sq_lds.json)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
