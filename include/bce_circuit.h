@@ -81,6 +81,10 @@ int bce_circuit_set_batched(bce_circuit*, int on);
 /* BinFHEContext::Encrypt output mode used by SetInput: BCE_FRESH (default) or BCE_BOOTSTRAPPED */
 int bce_circuit_set_encrypt_mode(bce_circuit*, int mode);
 
+/* opt-in extension, NOT reference semantics: evaluate XOR gates natively with OpenFHE's XOR_FAST
+ * (one bootstrap of 2*(ct1-ct2) instead of NOT,NOT,AND,AND,OR); the reference keeps this disabled
+ * because of its higher failure rate (src/gate.cpp:194-203) */
+int bce_circuit_set_xor_fast(bce_circuit*, int on);
 /* K independent input sets evaluated in lock-step (call before SetInput) */
 int bce_circuit_set_instances(bce_circuit*, uint32_t k);
 /* Circuit::SetInput, src/circuit.cpp:455-530: bits = concatenation of the input buses,

@@ -29,10 +29,10 @@ const char* op_name(GateEnum op) {
         default: return "?";
     }
 }
-uint32_t gate_weight(GateEnum op) {  // bootstraps per gate (src/gate.cpp:133,172,200-202)
+uint32_t gate_weight(GateEnum op, bool xor_fast = false) {  // bootstraps per gate (src/gate.cpp:133,172,200-202)
     switch (op) {
         case GateEnum::AND: case GateEnum::OR: return 1;
-        case GateEnum::XOR: return 3;
+        case GateEnum::XOR: return xor_fast ? 1 : 3;
         default: return 0;
     }
 }
@@ -115,7 +115,11 @@ void Gate::Evaluate(const GateEvalParams& gep) {
             break;
         case GateEnum::XOR:
             if (pt) { plainout.resize(1); plainout[0] = plainin[0] ^ plainin[1]; }
-            if (en) {
+            if (en && gep.xor_fast) {
+                bce_gate_desc d{BCE_XOR_FAST, encin[0], encin[1], enc_dst(), 0, 0};
+                gate_ck(gep, bce_eval_gates(gep.cc, 1, &d), name);
+                if (vf) verify_fix(gep, "XOR", encout[0], plainout[0], true, name);
+            } else if (en) {
                 // (a AND !b) OR (!a AND b), src/gate.cpp:198-202; the NOTs are folded into the prep
                 if (tmp.size() < 2) throw std::runtime_error("gate " + name + ": XOR needs two scratch slots");
                 bce_gate_desc a[2] = {{BCE_AND, encin[0], encin[1], tmp[0], 0, 1}, {BCE_AND, encin[0], encin[1], tmp[1], 1, 0}};
@@ -426,13 +430,13 @@ void Circuit::buildShardPlan() {
     for (size_t l = 0; l < Lc; ++l) {
         const auto& gl = levels_[l].gates;
         uint64_t total = 0;
-        for (int gi : gl) total += 4 * gate_weight(allGates[gi].op) + 1;  // NOT/OUTPUT weigh 1/4 bootstrap
+        for (int gi : gl) total += 4 * gate_weight(allGates[gi].op, xor_fast_) + 1;  // NOT/OUTPUT weigh 1/4 bootstrap
         uint64_t cum = 0;
         owner_[l].resize(gl.size());
         for (size_t k = 0; k < gl.size(); ++k) {
             const auto& g = allGates[gl[k]];
             uint8_t o = (uint8_t)std::min<uint64_t>(world_ - 1, cum * world_ / std::max<uint64_t>(total, 1));
-            cum += 4 * gate_weight(g.op) + 1;
+            cum += 4 * gate_weight(g.op, xor_fast_) + 1;
             if (g.op == GateEnum::OUTPUT) o = 0xFF;
             owner_[l][k] = o;
             gate_owner[gl[k]] = o;
@@ -585,7 +589,9 @@ void Circuit::executeRound(size_t level) {
             for (size_t k = 0; k < L.gates.size(); ++k) {
                 const GateRec& g = allGates[L.gates[k]];
                 const bool me = mine(k);
-                if (g.op == GateEnum::XOR) {
+                if (g.op == GateEnum::XOR && xor_fast_) {
+                    if (me) A.push_back({BCE_XOR_FAST, (uint32_t)g.in[0], (uint32_t)g.in[1], (uint32_t)g.out, 0, 0});
+                } else if (g.op == GateEnum::XOR) {
                     const uint32_t t1 = tmp0 + 2 * x, t2 = t1 + 1;
                     ++x;
                     if (!me) continue;
@@ -688,6 +694,8 @@ void Circuit::executeRound(size_t level) {
 
 Outputs Circuit::Clock() {
     if (done) throw std::logic_error("done ckt clocked! should reset");  // the reference exits (src/circuit.cpp:538-541)
+    if (!inputs_set_) throw std::logic_error("Clock: SetInput has not been called (no active wires)");
+    if (!plaintext_flag && !encrypted_flag) throw std::logic_error("Error either encrypted or plaintext flag must be set");
     auto t_total = Clock_t::now();
     double management = 0, execution = 0;
     uint64_t boots0 = 0;
@@ -755,7 +763,8 @@ bce_circuit_info Circuit::info() const {
         for (int gi : L.gates) {
             GateEnum op = allGates[gi].op;
             if (op == GateEnum::AND || op == GateEnum::OR) ++a;
-            if (op == GateEnum::XOR) { a += 2; ++b; }
+            if (op == GateEnum::XOR && xor_fast_) ++a;
+            else if (op == GateEnum::XOR) { a += 2; ++b; }
         }
         if (a) ++I.n_sublaunches;
         if (b) ++I.n_sublaunches;

@@ -58,6 +58,7 @@ public:
     bool encrypted_flag = false;
     bool verify_flag = false;
     bce_ctx* cc = nullptr;
+    bool xor_fast = false;            // opt-in: XOR as ONE bootstrap of 2*(ct1-ct2) (BCE_XOR_FAST), not the reference's 3
     uint64_t* enc_counter = nullptr;  // PRNG stream index for verify-mode re-encryptions
     unsigned int* fixes = nullptr;    // counts "Bad <OP> fixing" events
 };
@@ -115,6 +116,10 @@ public:
     unsigned getInstances() const { return instances_; }
     void setBatched(bool b) { batched_ = b; }
     void setEncryptMode(int mode) { encrypt_mode_ = mode; }
+    // opt-in, NOT the reference's semantics: evaluate XOR natively with OpenFHE's XOR_FAST gate
+    // (src/gate.cpp:194-196 disables it "for now" because of its higher failure rate)
+    void setXorFast(bool b) { xor_fast_ = gep.xor_fast = b; buildShardPlan(); }
+    bool getXorFast() const { return xor_fast_; }
     void setQuiet(bool q) { quiet_ = q; }
     // re-arm for another Clock() on the SAME inputs: keeps mode flags and the input ciphertexts
     // already resident in the device pool (registers are SSA, inputs are never overwritten)
@@ -146,7 +151,7 @@ private:
     bce_ctx* cc = nullptr;
     bool owns_engine_ = false;
     bool plaintext_flag = false, encrypted_flag = false, verify_flag = false;
-    bool done = false, inputs_set_ = false, quiet_ = false, batched_ = true;
+    bool done = false, inputs_set_ = false, quiet_ = false, batched_ = true, xor_fast_ = false;
     int encrypt_mode_ = BCE_FRESH;
     GateEvalParams gep;
 

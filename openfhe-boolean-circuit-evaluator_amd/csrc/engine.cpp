@@ -124,7 +124,9 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     }
     if (device < 0 || device >= ndev) { g_create_error = "bad device ordinal"; return BCE_ERR_ARG; }
 
-    std::unique_ptr<bce_ctx> c(new bce_ctx);
+    // partially built contexts are released through bce_ctx_destroy (frees whatever was allocated)
+    struct CtxDeleter { void operator()(bce_ctx* p) const { bce_ctx_destroy(p); } };
+    std::unique_ptr<bce_ctx, CtxDeleter> c(new bce_ctx);
     c->n = n; c->N = N; c->q = q; c->Q = Q; c->qKS = qKS ? qKS : Q;
     c->baseKS = baseKS; c->baseG = baseG; c->baseR = baseR; c->method = method; c->device = device;
     while ((1u << c->logN) < N) ++c->logN;

@@ -178,3 +178,17 @@ def test_k_instances_in_lock_step(bce, asm_dir):
     c.Clock()
     for k, (_, want) in enumerate(cases):
         assert c.Outputs(k)[0] == want
+
+
+def test_clock_needs_inputs_and_a_mode(bce):
+    c = bce.Circuit()
+    c.ReadFile(os.path.join(CIRCUITS, "adder_2bit.out"))
+    c.Reset()
+    c.setPlaintext(True)
+    with pytest.raises(bce.BceError):
+        c.Clock()                              # no SetInput
+    c.Reset()
+    c.SetInput([[1, 0], [0, 1]])
+    with pytest.raises(bce.BceError) as e:     # neither plaintext nor encrypted (src/circuit.cpp:803-806)
+        c.Clock()
+    assert "flag must be set" in str(e.value)

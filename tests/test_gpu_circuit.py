@@ -173,3 +173,48 @@ def test_sha256_new_format_std128_four_vectors_in_lock_step(bce, std_cc):
     st = c.stats()
     assert st["bootstraps"] == 354505 * len(vecs)
     print("sha256 x%d: %.1f s, %.0f bootstraps/s" % (len(vecs), st["total_ms"] / 1e3, st["bootstraps"] / st["total_ms"] * 1e3))
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_verify_mode_repairs_an_injected_fault(bce, toy_cc, batched):
+    """Fault injection for the reference's verify-and-fix path (src/gate.cpp:153-160): the ciphertext of
+    input register R0 is replaced by an encryption of the WRONG bit after SetInput, so the encrypted pass
+    disagrees with the plaintext pass at the first gates; verify mode must log 'Bad <OP> fixing', re-encrypt
+    the right value and still deliver the correct sum."""
+    c = bce.Circuit(toy_cc)
+    c.ReadFile(os.path.join(CIRCUITS, "adder_2bit.out"))
+    c.setBatched(batched)
+    c.Reset()
+    c.setVerify(True)                       # forces plaintext + encrypted
+    c.SetInput([[1, 0], [1, 1]])            # a = 1, b = 3
+    toy_cc.Encrypt([0], [0], enc_index_base=123456)   # R0 (a bit 0) now encrypts 0 instead of 1
+    out = c.Clock()[0]
+    assert out[0] + 2 * out[1] + 4 * out[2] == 4
+    assert c.stats()["verify_fixes"] >= 2   # R4 = XOR(R0,R2) and R5 = AND(R0,R2) were wrong and got repaired
+    # without verify the same fault propagates to the output (the encrypted path really used the bad input)
+    c.Reset()
+    c.setEncrypted(True)
+    c.SetInput([[1, 0], [1, 1]])
+    toy_cc.Encrypt([0], [0], enc_index_base=123457)
+    out = c.Clock()[0]
+    assert out[0] + 2 * out[1] + 4 * out[2] == 3   # 0 + 3
+
+
+def test_xor_fast_opt_in(bce, toy_cc, std_cc):
+    """opt-in native XOR: one XOR_FAST bootstrap per XOR gate; bootstrap count drops from
+    XOR=3 to XOR=1; functional result unchanged (noise behaviour differs, hence not the parity mode)"""
+    c = bce.Circuit(toy_cc)
+    c.ReadFile(os.path.join(CIRCUITS, "adder_2bit.out"))
+    c.setXorFast(True)
+    assert c.info()["n_bootstraps"] == 3 * 1 + 3 + 1
+    for a in range(4):
+        for b in range(4):
+            o = _enc_run(c, [[a & 1, a >> 1], [b & 1, b >> 1]])
+            assert o[0] + 2 * o[1] + 4 * o[2] == a + b
+    assert c.stats()["bootstraps"] == 7
+    m = bce.Circuit(std_cc)
+    m.ReadBristol(os.path.join(CIRCUITS, "AES-expanded.txt"))
+    m.setXorFast(True)
+    assert m.info()["n_bootstraps"] == 25765
+    v = [x for x in kat.AES_VECTORS if x["circuit"] == "AES-expanded"][1]
+    assert _enc_run(m, kat.aes_case(v)[0]) == kat.aes_case(v)[1]
