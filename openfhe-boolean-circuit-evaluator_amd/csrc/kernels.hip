@@ -688,16 +688,20 @@ __global__ __launch_bounds__(256) void k_tail(DevParams P, const bce_gate_desc* 
     const bce_gate_desc g = descs[blockIdx.x % n_desc];
     u32* out = P.pool + (size_t)(g.out + (blockIdx.x / n_desc) * slot_stride) * P.pool_stride;
     for (u32 k = tid; k <= n; k += T) {
-        ACC s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        // row gather: 16 independent loads in flight per thread (the loop is latency-bound otherwise)
+        constexpr u32 U = 16;
+        ACC acc[U];
+#pragma unroll
+        for (u32 u = 0; u < U; ++u) acc[u] = 0;
         u32 r = 0;
-        for (; r + 4 <= rows; r += 4) {
-            s0 += ksk[(size_t)rowidx[r] * P.ksk_stride + k];
-            s1 += ksk[(size_t)rowidx[r + 1] * P.ksk_stride + k];
-            s2 += ksk[(size_t)rowidx[r + 2] * P.ksk_stride + k];
-            s3 += ksk[(size_t)rowidx[r + 3] * P.ksk_stride + k];
+        for (; r + U <= rows; r += U) {
+#pragma unroll
+            for (u32 u = 0; u < U; ++u) acc[u] += ksk[(size_t)rowidx[r + u] * P.ksk_stride + k];
         }
-        for (; r < rows; ++r) s0 += ksk[(size_t)rowidx[r] * P.ksk_stride + k];
-        u64 sum = (u64)s0 + (u64)s1 + (u64)s2 + (u64)s3;
+        for (; r < rows; ++r) acc[0] += ksk[(size_t)rowidx[r] * P.ksk_stride + k];
+        u64 sum = 0;
+#pragma unroll
+        for (u32 u = 0; u < U; ++u) sum += (u64)acc[u];
         u32 sm = (u32)(sum % qKS);
         u32 base = (k == n) ? s_b : 0u;
         u32 v = base >= sm ? base - sm : base + qKS - sm;
