@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--circuit", default="AES-expanded.txt")
     ap.add_argument("--paramset", default="STD128_OPT")
     ap.add_argument("--shard", choices=["instances", "gates"], default="instances")
+    ap.add_argument("--relevel", action="store_true", help="opt-in bootstrap-depth schedule (same ciphertexts, fewer launches)")
+    ap.add_argument("--xor-fast", action="store_true", help="opt-in native XOR (NOT the reference's XOR = 3 bootstraps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
@@ -117,6 +119,10 @@ def main():
     circ = bce.Circuit(cc)
     path = os.path.join(ROOT, "tests", "golden", "circuits", args.circuit)
     circ.ReadBristol(path, new_flag=args.circuit.startswith("sha256_new"))
+    if args.xor_fast:
+        circ.setXorFast(True)
+    if args.relevel:
+        circ.setRelevel(True)
     info = circ.info()
     shard_mode = 0 if args.shard == "instances" else 1
     K_total = args.instances * world if shard_mode == 0 else args.instances
@@ -187,7 +193,8 @@ def main():
     traffic = None
     try:  # HBM/fabric bytes per launch from the committed --pmc passes of this same default command
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if args.instances == 16 and args.circuit == "AES-expanded.txt" and args.paramset == "STD128_OPT" and shard_mode == 0:
+        if (args.instances == 16 and args.circuit == "AES-expanded.txt" and args.paramset == "STD128_OPT" and shard_mode == 0
+                and not args.relevel and not args.xor_fast):
             traffic = tj["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -216,6 +223,8 @@ def main():
                                 args.circuit, info["n_gates"] - info["n_output_bits"], info["n_bootstraps"],
                                 info["n_sublaunches"], args.paramset, args.instances),
                 "instances_per_gpu": args.instances, "sharding": args.shard,
+                "schedule": "re-levelled (opt-in)" if args.relevel else "gate levels (reference semantics)",
+                "xor": "XOR_FAST (opt-in, 1 bootstrap)" if args.xor_fast else "NOT,NOT,AND,AND,OR (reference, 3 bootstraps)",
                 "bootstraps_per_step": int(total_boot / args.steps),
                 "outputs_verified": bool(verified), "setup_s": round(setup_s, 2),
                 "host_share_of_step": round(1.0 - (tm["blind_rotate_ms"] + tm["tail_ms"]) / (elapsed * 1e3), 4),

@@ -32,6 +32,7 @@ typedef struct bce_circuit_info {
     uint32_t n_output_bits;  /* max STORE index + 1 (single output bus)                  */
     uint32_t n_levels;       /* Clock() rounds = ASAP levels incl. NOT and OUTPUT levels */
     uint32_t n_sublaunches;  /* dependent bce_eval_gates launches per evaluation          */
+    uint32_t n_relevel_steps;/* dependent launches of the opt-in re-levelled schedule     */
     uint32_t max_frontier;   /* widest sub-launch, in bootstraps                          */
     uint64_t n_bootstraps;   /* per evaluation: AND=1, OR=1, XOR=3, NOT=0                 */
 } bce_circuit_info;
@@ -85,6 +86,9 @@ int bce_circuit_set_encrypt_mode(bce_circuit*, int mode);
  * (one bootstrap of 2*(ct1-ct2) instead of NOT,NOT,AND,AND,OR); the reference keeps this disabled
  * because of its higher failure rate (src/gate.cpp:194-203) */
 int bce_circuit_set_xor_fast(bce_circuit*, int on);
+/* opt-in extension: schedule by bootstrap depth (NOTs folded into consumers, an XOR's OR launched with
+ * the next level's ANDs).  Same ciphertexts, fewer dependent launches; encrypted-only runs, no verify. */
+int bce_circuit_set_relevel(bce_circuit*, int on);
 /* K independent input sets evaluated in lock-step (call before SetInput) */
 int bce_circuit_set_instances(bce_circuit*, uint32_t k);
 /* Circuit::SetInput, src/circuit.cpp:455-530: bits = concatenation of the input buses,

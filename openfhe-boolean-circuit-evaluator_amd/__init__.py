@@ -270,7 +270,8 @@ class BinFHEContext:
 class CircuitInfo(C.Structure):
     _fields_ = [("n_gates", C.c_uint32), ("n_input_gates", C.c_uint32), ("n_wires", C.c_uint32),
                 ("n_inputs", C.c_uint32), ("n_input_bits", C.c_uint32 * 2), ("n_output_bits", C.c_uint32),
-                ("n_levels", C.c_uint32), ("n_sublaunches", C.c_uint32), ("max_frontier", C.c_uint32),
+                ("n_levels", C.c_uint32), ("n_sublaunches", C.c_uint32), ("n_relevel_steps", C.c_uint32),
+                ("max_frontier", C.c_uint32),
                 ("n_bootstraps", C.c_uint64)]
 
 
@@ -286,7 +287,7 @@ CIRCUIT_SYMBOLS = [
     "bce_circuit_create", "bce_circuit_destroy", "bce_circuit_last_error", "bce_circuit_read_file",
     "bce_circuit_read_bristol", "bce_circuit_get_info", "bce_circuit_reset", "bce_circuit_rearm", "bce_circuit_set_plaintext",
     "bce_circuit_set_encrypted", "bce_circuit_set_verify", "bce_circuit_get_flags", "bce_circuit_set_batched",
-    "bce_circuit_set_encrypt_mode", "bce_circuit_set_xor_fast", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
+    "bce_circuit_set_encrypt_mode", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
     "bce_circuit_get_output", "bce_circuit_get_counts", "bce_circuit_get_stats", "bce_circuit_dump",
     "bce_circuit_set_exchange", "bce_circuit_exchange_capacity", "bce_assemble_bristol", "bce_pool_gather",
     "bce_pool_scatter",
@@ -311,7 +312,7 @@ def _bind_circuit():
     L.bce_circuit_get_info.argtypes = [vp, C.POINTER(CircuitInfo)]
     for name in ("reset", "rearm", "clock"):
         getattr(L, "bce_circuit_" + name).argtypes = [vp]
-    for name in ("set_plaintext", "set_encrypted", "set_verify", "set_batched", "set_encrypt_mode", "set_xor_fast", "dump"):
+    for name in ("set_plaintext", "set_encrypted", "set_verify", "set_batched", "set_encrypt_mode", "set_xor_fast", "set_relevel", "dump"):
         getattr(L, "bce_circuit_" + name).argtypes = [vp, i32]
     L.bce_circuit_get_flags.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.bce_circuit_set_instances.argtypes = [vp, u32]
@@ -435,6 +436,10 @@ class Circuit:
     def setXorFast(self, b):
         """opt-in, not reference semantics: XOR as one XOR_FAST bootstrap"""
         self._ck(self._L.bce_circuit_set_xor_fast(self.h, int(b)))
+
+    def setRelevel(self, b):
+        """opt-in: bootstrap-depth schedule (fewer dependent launches, same ciphertexts)"""
+        self._ck(self._L.bce_circuit_set_relevel(self.h, int(b)))
 
     def setInstances(self, k):
         self._ck(self._L.bce_circuit_set_instances(self.h, int(k)))

@@ -337,6 +337,8 @@ void Circuit::finalizeNetlist() {
         levels_.push_back(std::move(L));
     }
     stride_ = (uint32_t)W + 2 * max_level_xor_;
+    buildRelevelPlan();  // also sizes the scratch slots the re-levelled schedule needs
+    stride_ = std::max(stride_, relevel_stride_);
     buildShardPlan();
     Reset();
 }
@@ -550,6 +552,121 @@ void Circuit::gatherOutputs() {
     ++stats_.exchanges;
 }
 
+// ---- re-levelled (bootstrap-depth) schedule: SURVEY 8(f2) -------------------------------------------
+void Circuit::buildRelevelPlan() {
+    const size_t W = wire_names_.size(), G = allGates.size();
+    // resolve NOT chains: wire -> (base wire, negated)
+    std::vector<int> base(W), producer(W, -1);
+    std::vector<uint8_t> neg(W, 0);
+    for (size_t w = 0; w < W; ++w) base[w] = (int)w;
+    for (size_t gi = 0; gi < G; ++gi) if (allGates[gi].out >= 0) producer[allGates[gi].out] = (int)gi;
+    // gates are in topological (file) order per level; walk levels so that bases are resolved first
+    std::vector<uint32_t> depth(W, 0);
+    struct Node { uint32_t depth; bce_gate_desc d; };
+    std::vector<Node> nodes;
+    std::vector<uint32_t> xor_at_depth;  // XOR count whose ANDs sit at a depth (temp slot allocation)
+    auto bump = [&](uint32_t d) { if (xor_at_depth.size() <= d) xor_at_depth.resize(d + 1, 0); return xor_at_depth[d]++; };
+    struct PendingXor { uint32_t d, idx; GateRec g; uint32_t in0, in1, n0, n1; };
+    std::vector<PendingXor> xors;
+    for (const auto& L : levels_)
+        for (int gi : L.gates) {
+            const GateRec& g = allGates[gi];
+            if (g.op == GateEnum::NOT) {
+                base[g.out] = base[g.in[0]];
+                neg[g.out] = neg[g.in[0]] ^ 1;
+                depth[g.out] = depth[g.in[0]];
+            } else if (g.op == GateEnum::AND || g.op == GateEnum::OR || g.op == GateEnum::XOR) {
+                const uint32_t b0 = (uint32_t)base[g.in[0]], b1 = (uint32_t)base[g.in[1]];
+                const uint32_t n0 = neg[g.in[0]], n1 = neg[g.in[1]];
+                const uint32_t d = 1 + std::max(depth[g.in[0]], depth[g.in[1]]);
+                if (g.op != GateEnum::XOR) {
+                    nodes.push_back({d, {(uint32_t)(g.op == GateEnum::AND ? BCE_AND : BCE_OR), b0, b1, (uint32_t)g.out, n0, n1}});
+                    depth[g.out] = d;
+                } else if (xor_fast_) {
+                    // XOR_FAST of negated inputs: NOT a XOR NOT b = a XOR b; one negation flips the result
+                    nodes.push_back({d, {(uint32_t)((n0 ^ n1) ? BCE_XNOR_FAST : BCE_XOR_FAST), b0, b1, (uint32_t)g.out, 0, 0}});
+                    depth[g.out] = d;
+                } else {
+                    xors.push_back({d, bump(d), g, b0, b1, n0, n1});
+                    depth[g.out] = d + 1;
+                }
+            }
+        }
+    uint32_t max_x = 0;
+    for (uint32_t c : xor_at_depth) max_x = std::max(max_x, c);
+    const uint32_t tmp0 = (uint32_t)W;
+    relevel_stride_ = tmp0 + 4 * max_x;  // two parity banks of 2 temporaries per XOR
+    for (const auto& x : xors) {
+        const uint32_t t1 = tmp0 + (x.d & 1) * 2 * max_x + 2 * x.idx, t2 = t1 + 1;
+        // (a AND !b), (!a AND b) with the inputs' own negations folded in, then OR one step later
+        nodes.push_back({x.d, {BCE_AND, x.in0, x.in1, t1, x.n0, x.n1 ^ 1u}});
+        nodes.push_back({x.d, {BCE_AND, x.in0, x.in1, t2, x.n0 ^ 1u, x.n1}});
+        nodes.push_back({x.d + 1, {BCE_OR, t1, t2, (uint32_t)x.g.out, 0, 0}});
+    }
+    uint32_t D = 0;
+    for (const auto& nd : nodes) D = std::max(D, nd.depth);
+    relevel_plan_.assign(D, RStep{});
+    for (const auto& nd : nodes) relevel_plan_[nd.depth - 1].descs.push_back(nd.d);
+    // NOT wires consumed by OUTPUT gates need a real ciphertext (decrypt must see EvalNOT's output)
+    relevel_nots_.clear();
+    std::vector<uint8_t> done_not(W, 0);
+    for (const auto& g : allGates)
+        if (g.op == GateEnum::OUTPUT && neg[g.in[0]] && !done_not[g.in[0]]) {
+            done_not[g.in[0]] = 1;
+            relevel_nots_.push_back({BCE_OP_NOT, (uint32_t)base[g.in[0]], (uint32_t)base[g.in[0]], (uint32_t)g.in[0], 0, 0});
+        } else if (g.op == GateEnum::OUTPUT && !neg[g.in[0]] && base[g.in[0]] != g.in[0] && !done_not[g.in[0]]) {
+            done_not[g.in[0]] = 1;  // double negation: plain copy of the base
+            relevel_nots_.push_back({BCE_OP_COPY, (uint32_t)base[g.in[0]], (uint32_t)base[g.in[0]], (uint32_t)g.in[0], 0, 0});
+        }
+}
+
+void Circuit::setXorFast(bool b) {
+    xor_fast_ = gep.xor_fast = b;
+    buildShardPlan();
+    buildRelevelPlan();
+}
+
+void Circuit::clockReleveled() {
+    if (world_ > 1 && shard_mode_ == 1) throw std::logic_error("re-levelled schedule is not available with gate sharding");
+    if (verify_flag) throw std::logic_error("re-levelled schedule is not available in verify mode");
+    if (relevel_plan_.empty()) buildRelevelPlan();
+    unsigned lo, hi;
+    instanceRange(lo, hi);
+    const uint32_t K = hi - lo;
+    if (relevel_stride_ > stride_) throw std::logic_error("re-levelled schedule needs more scratch slots than the pool stride");
+    auto launch = [&](const std::vector<bce_gate_desc>& src) {
+        if (src.empty()) return;
+        std::vector<bce_gate_desc> d(src);
+        for (auto& e : d) { e.in0 += lo * stride_; e.in1 += lo * stride_; e.out += lo * stride_; }
+        ck(bce_eval_gates_strided(cc, (uint32_t)d.size(), d.data(), K, stride_), "Clock(re-levelled step)");
+        ++stats_.sublaunches;
+    };
+    for (const auto& st : relevel_plan_) launch(st.descs);
+    launch(relevel_nots_);
+    // OUTPUT gates
+    std::vector<uint32_t> oslots;
+    std::vector<std::pair<unsigned, int>> obits;
+    for (const auto& g : allGates)
+        if (g.op == GateEnum::OUTPUT)
+            for (unsigned i = lo; i < hi; ++i) { oslots.push_back(i * stride_ + g.in[0]); obits.push_back({i, g.out_bit}); }
+    if (!oslots.empty()) {
+        std::vector<uint8_t> res(oslots.size());
+        ck(bce_decrypt_bits(cc, oslots.data(), (uint32_t)oslots.size(), res.data()), "Clock(Decrypt)");
+        for (size_t k = 0; k < oslots.size(); ++k) circuitOut[obits[k].first][obits[k].second] = res[k];
+    }
+    for (const auto& g : allGates) {
+        switch (g.op) {
+            case GateEnum::OUTPUT: ++n_output_gates; break;
+            case GateEnum::NOT: ++n_not_gates; break;
+            case GateEnum::AND: ++n_and_gates; break;
+            case GateEnum::OR: ++n_or_gates; break;
+            case GateEnum::XOR: ++n_xor_gates; break;
+            default: break;
+        }
+    }
+    stats_.levels = (uint32_t)relevel_plan_.size();
+}
+
 // ---- Clock -------------------------------------------------------------------------------------
 void Circuit::managerRound(size_t) {
     // Readiness was resolved once in finalizeNetlist(); the per-round work the reference does here
@@ -707,7 +824,14 @@ Outputs Circuit::Clock() {
         boots0 = t.bootstraps;
     }
     size_t done_gates = 0;
-    for (size_t l = 0; l < levels_.size() && inputs_set_; ++l) {
+    const bool releveled = relevel_ && encrypted_flag && !plaintext_flag;
+    if (releveled) {
+        auto t0 = Clock_t::now();
+        clockReleveled();
+        execution += ms_since(t0);
+        done_gates = allGates.size();
+    }
+    for (size_t l = 0; l < levels_.size() && inputs_set_ && !releveled; ++l) {
         auto t0 = Clock_t::now();
         managerRound(l);
         management += ms_since(t0);
@@ -758,6 +882,7 @@ bce_circuit_info Circuit::info() const {
     I.n_input_bits[1] = n_in_bits_[1];
     I.n_output_bits = n_output_bits.empty() ? 0 : n_output_bits[0];
     I.n_levels = (uint32_t)levels_.size();
+    I.n_relevel_steps = (uint32_t)relevel_plan_.size();
     for (const auto& L : levels_) {
         uint32_t a = 0, b = 0;
         for (int gi : L.gates) {

@@ -118,7 +118,12 @@ public:
     void setEncryptMode(int mode) { encrypt_mode_ = mode; }
     // opt-in, NOT the reference's semantics: evaluate XOR natively with OpenFHE's XOR_FAST gate
     // (src/gate.cpp:194-196 disables it "for now" because of its higher failure rate)
-    void setXorFast(bool b) { xor_fast_ = gep.xor_fast = b; buildShardPlan(); }
+    void setXorFast(bool b);
+    // opt-in: schedule by BOOTSTRAP depth instead of gate level -- NOT gates are folded into their
+    // consumers' prep (neg flags) and an XOR's OR shares a launch with the next level's ANDs.  Same
+    // ciphertexts as the level schedule (EvalNOT is deterministic), fewer dependent launches.
+    void setRelevel(bool b) { relevel_ = b; }
+    bool getRelevel() const { return relevel_; }
     bool getXorFast() const { return xor_fast_; }
     void setQuiet(bool q) { quiet_ = q; }
     // re-arm for another Clock() on the SAME inputs: keeps mode flags and the input ciphertexts
@@ -190,6 +195,13 @@ private:
     void finalizeNetlist();
     void buildShardPlan();
     void instanceRange(unsigned& lo, unsigned& hi) const;
+    struct RStep { std::vector<bce_gate_desc> descs; };
+    bool relevel_ = false;
+    std::vector<RStep> relevel_plan_;          // bootstrap-depth schedule (built lazily)
+    std::vector<bce_gate_desc> relevel_nots_;  // NOT wires that OUTPUT gates read: materialised at the end
+    uint32_t relevel_stride_ = 0;
+    void buildRelevelPlan();
+    void clockReleveled();
     void managerRound(size_t level);
     void executeRound(size_t level);
     void exchangeLevel(size_t level);

@@ -80,6 +80,7 @@ int bce_circuit_set_encrypt_mode(bce_circuit* h, int mode) {
     });
 }
 int bce_circuit_set_xor_fast(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setXorFast(on != 0); }); }
+int bce_circuit_set_relevel(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setRelevel(on != 0); }); }
 int bce_circuit_set_instances(bce_circuit* h, uint32_t k) { return guarded(h, [&] { h->c.setInstances(k); }); }
 
 int bce_circuit_set_input(bce_circuit* h, uint32_t instance, const uint32_t* widths, uint32_t n_buses, const uint8_t* bits) {

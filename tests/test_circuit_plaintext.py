@@ -192,3 +192,17 @@ def test_clock_needs_inputs_and_a_mode(bce):
     with pytest.raises(bce.BceError) as e:     # neither plaintext nor encrypted (src/circuit.cpp:803-806)
         c.Clock()
     assert "flag must be set" in str(e.value)
+
+
+def test_relevelled_schedule_depths_match_the_survey(bce, asm_dir):
+    """SURVEY.md App. C, column 're-levelled: steps' (ASAP over bootstraps only, NOT free, XOR depth 2)"""
+    want = {"adder_32bit.txt": 63, "adder_64bit.txt": 127, "mult_32x32.txt": 132, "AES-expanded.txt": 416,
+            "AES-non-expanded.txt": 420, "md5.txt": 3852, "comparator_32bit_signed_lt.txt": 22,
+            "comparator_32bit_unsigned_lteq.txt": 21}
+    for name, steps in want.items():
+        c = bce.Circuit()
+        c.ReadBristol(os.path.join(CIRCUITS, name))
+        assert c.info()["n_relevel_steps"] == steps, name
+    c = bce.Circuit()
+    c.ReadBristol(os.path.join(CIRCUITS, "sha256_new.txt"), new_flag=True)
+    assert c.info()["n_relevel_steps"] == 9055

@@ -218,3 +218,29 @@ def test_xor_fast_opt_in(bce, toy_cc, std_cc):
     assert m.info()["n_bootstraps"] == 25765
     v = [x for x in kat.AES_VECTORS if x["circuit"] == "AES-expanded"][1]
     assert _enc_run(m, kat.aes_case(v)[0]) == kat.aes_case(v)[1]
+
+
+def test_relevelled_schedule_same_ciphertexts_fewer_launches(bce, toy_cc, std_cc):
+    """opt-in bootstrap-depth schedule: identical register ciphertexts, fewer launches"""
+    c = bce.Circuit(toy_cc)
+    c.ReadFile(os.path.join(CIRCUITS, "parity.out"))        # has NOT gates, one of them feeds an OUTPUT
+    ins, want = kat.parity_case(3)
+    c.Reset(); c.setEncrypted(True); c.SetInput(ins)
+    assert c.Clock()[0] == want
+    lvl = toy_cc.lwe_read(np.arange(0, 27, dtype=np.uint32))
+    n_lvl = c.stats()["sublaunches"]
+    c.setRelevel(True)
+    c.Rearm()
+    assert c.Clock()[0] == want
+    rel = toy_cc.lwe_read(np.arange(0, 27, dtype=np.uint32))
+    xor_regs = [18, 19, 20, 21, 22, 23, 24, 25]             # bootstrapped registers of parity.out
+    assert np.array_equal(lvl[xor_regs], rel[xor_regs])
+    assert np.array_equal(lvl[26], rel[26])                  # R26 = NOT(R25), read by Out1
+    assert c.stats()["sublaunches"] < n_lvl
+    m = bce.Circuit(std_cc)
+    m.ReadBristol(os.path.join(CIRCUITS, "AES-expanded.txt"))
+    m.setRelevel(True)
+    v = [x for x in kat.AES_VECTORS if x["circuit"] == "AES-expanded"][0]
+    assert _enc_run(m, kat.aes_case(v)[0]) == kat.aes_case(v)[1]
+    st = m.stats()
+    assert st["bootstraps"] == 66415 and st["sublaunches"] == 416 + 0 and st["levels"] == 416
