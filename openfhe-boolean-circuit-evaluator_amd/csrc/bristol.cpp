@@ -40,9 +40,16 @@ Analysis analyze_bristol(const std::string& in_fname, bool gen_fan_flag, bool ne
             if (!(s >> v.n_in2_bits)) v.n_in2_bits = 0;
         }
         if (!next_line(f, line)) throw std::runtime_error("analyze_bristol: truncated header");
-        std::istringstream(line) >> n_out >> v.n_out1_bits;
-        if (v.n_inputs > 2 || n_out != 1)
-            throw std::runtime_error("analyze_bristol: only <=2 input buses and 1 output bus are supported");
+        {
+            // "<n_outputs> <w1> [<w2> ...]": several outputs are concatenated on the single output bus the
+            // driver has (outputs are the last sum(w) wires, first output first)
+            std::istringstream so(line);
+            so >> n_out;
+            v.n_out1_bits = 0;
+            for (unsigned k = 0, w = 0; k < n_out && (so >> w); ++k) v.n_out1_bits += w;
+        }
+        if (v.n_inputs > 2 || n_out < 1)
+            throw std::runtime_error("analyze_bristol: only <=2 input buses are supported");
         next_line(f, line);
     } else {
         // "<n_in1> <n_in2> <n_out>" / blank  (src/analyze.cpp:160-179)

@@ -284,6 +284,11 @@ bool Circuit::ReadBristol(const std::string& path, bool new_flag) {
             g.op = op == "XOR" ? GateEnum::XOR : GateEnum::AND; g.nin = 2; g.in[0] = node_wire[il[0]]; g.in[1] = node_wire[il[1]];
         } else if (op == "NOT") {
             g.op = GateEnum::NOT; g.nin = 1; g.in[0] = node_wire[il.at(0)];
+        } else if (op == "EQW") {
+            // Bristol Fashion wire copy: no gate, the output node is an alias of the input wire
+            // (the reference's assembler only emits a parse-error comment for it, src/assemble.cpp:370-373)
+            node_wire[f.out_list[i].at(0)] = node_wire[il.at(0)];
+            continue;
         } else {
             throw std::runtime_error("ReadBristol: unsupported op " + op + " at gate " + std::to_string(i));
         }

@@ -206,3 +206,32 @@ def test_relevelled_schedule_depths_match_the_survey(bce, asm_dir):
     c = bce.Circuit()
     c.ReadBristol(os.path.join(CIRCUITS, "sha256_new.txt"), new_flag=True)
     assert c.info()["n_relevel_steps"] == 9055
+
+
+def _bits(v, n):
+    return [(v >> i) & 1 for i in range(n)]
+
+
+def test_new_format_arithmetic_circuits(bce):
+    """Bristol Fashion (new format) circuits read directly: 2 inputs / 1 output, EQW wire copies (neg64) and
+    two outputs concatenated on the single output bus (mult2_64).  LSB-first wires."""
+    import random
+    rnd = random.Random(7)
+    M = (1 << 64) - 1
+
+    def run(name, a, b=None):
+        c = bce.Circuit()
+        c.ReadBristol(os.path.join(CIRCUITS, name), new_flag=True)
+        ins = [_bits(a, 64)] + ([_bits(b, 64)] if b is not None else [])
+        return kat.to_int(_run(c, ins)), c.info()
+
+    for _ in range(3):
+        a, b = rnd.getrandbits(64), rnd.getrandbits(64)
+        assert run("adder64.txt", a, b)[0] == (a + b) & M
+        assert run("sub64.txt", a, b)[0] == (a - b) & M
+        assert run("neg64.txt", a)[0] == (-a) & M
+        assert run("mult64.txt", a, b)[0] == (a * b) & M
+        got, info = run("mult2_64.txt", a, b)          # two 64-bit outputs: high half first, then low half
+        assert info["n_output_bits"] == 128 and got == ((a * b) >> 64) | (((a * b) & M) << 64)
+        assert run("udivide64.txt", a, b | 1)[0] == a // (b | 1)
+    assert run("zero_equal.txt", 0)[0] == 1 and run("zero_equal.txt", 5)[0] == 0
