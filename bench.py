@@ -3,7 +3,7 @@
 
 One "step" = one full encrypted evaluation (Circuit::Clock, verify off) of AES-expanded
 (old Bristol, 27,692 gates = 66,415 gate bootstraps) on K independent input blocks evaluated in
-lock-step per GPU; every ready frontier goes through bce_eval_gates_strided() to the HIP
+lock-step per GPU (K = 32 by default); every ready frontier goes through bce_eval_gates_strided() to the HIP
 blind-rotation + key-switch kernels.  Keys, parsing and input encryption are outside the timed
 region (input ciphertexts are resident in HBM when timing starts).  Multi-GPU (`--gpus N`, one
 rank per GPU under torch.distributed.run): keys replicated from the same seed, instances sharded
@@ -82,11 +82,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=16, help="AES blocks evaluated in lock-step per GPU")
+    ap.add_argument("--instances", type=int, default=32, help="AES blocks evaluated in lock-step per GPU")
     ap.add_argument("--circuit", default="AES-expanded.txt")
     ap.add_argument("--paramset", default="STD128_OPT")
     ap.add_argument("--shard", choices=["instances", "gates"], default="instances")
-    ap.add_argument("--relevel", action="store_true", help="opt-in bootstrap-depth schedule (same ciphertexts, fewer launches)")
+    ap.add_argument("--no-relevel", dest="relevel", action="store_false",
+                    help="schedule by gate level exactly like the reference's Clock() rounds (496 launches for AES) instead of "
+                         "by bootstrap depth (416 launches, identical ciphertexts)")
+    ap.set_defaults(relevel=True)
     ap.add_argument("--xor-fast", action="store_true", help="opt-in native XOR (NOT the reference's XOR = 3 bootstraps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -193,8 +196,8 @@ def main():
     traffic = None
     try:  # HBM/fabric bytes per launch from the committed --pmc passes of this same default command
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if (args.instances == 16 and args.circuit == "AES-expanded.txt" and args.paramset == "STD128_OPT" and shard_mode == 0
-                and not args.relevel and not args.xor_fast):
+        if (args.instances == tj.get("instances_per_gpu") and args.circuit == "AES-expanded.txt" and args.paramset == "STD128_OPT"
+                and shard_mode == 0 and args.relevel == tj.get("relevel") and not args.xor_fast):
             traffic = tj["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -223,7 +226,7 @@ def main():
                                 args.circuit, info["n_gates"] - info["n_output_bits"], info["n_bootstraps"],
                                 info["n_sublaunches"], args.paramset, args.instances),
                 "instances_per_gpu": args.instances, "sharding": args.shard,
-                "schedule": "re-levelled (opt-in)" if args.relevel else "gate levels (reference semantics)",
+                "schedule": "bootstrap-depth levels (NOTs folded, identical ciphertexts)" if args.relevel else "gate levels (reference Clock rounds)",
                 "xor": "XOR_FAST (opt-in, 1 bootstrap)" if args.xor_fast else "NOT,NOT,AND,AND,OR (reference, 3 bootstraps)",
                 "bootstraps_per_step": int(total_boot / args.steps),
                 "outputs_verified": bool(verified), "setup_s": round(setup_s, 2),
