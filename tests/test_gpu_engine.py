@@ -306,3 +306,34 @@ def test_std192_gate_same_seed_keys(bce, orc, method):
     assert list(c.Decrypt([2, 3])) == [0, 1]
     o.close()
     c.close()
+
+
+def test_two_host_threads_on_distinct_contexts(bce, orc):
+    """SURVEY 8(b) threading row: eval_gates is called from one host thread per context; distinct contexts
+    may be driven concurrently from different host threads (ctypes releases the GIL during the calls)."""
+    import threading
+    results = {}
+
+    def worker(tag, seed):
+        o = orc.Oracle(orc.TOY, orc.GINX)
+        o.keygen(seed)
+        c = bce.BinFHEContext(bce.TOY, bce.GINX)
+        c.KeyGen(seed)
+        c.pool_reserve(64)
+        ok = True
+        for rep in range(6):
+            ca, cb = o.encrypt(rep & 1, 2 * rep), o.encrypt(1, 2 * rep + 1)
+            c.lwe_write([0, 1], np.stack([ca, cb]))
+            c.EvalGates([(bce.NAND, 0, 1, 2), (bce.OR, 0, 1, 3), (bce.AND, 0, 1, 4, 1, 0)])
+            out = c.lwe_read([2, 3, 4])
+            ok &= np.array_equal(out[0], o.eval_bingate(bce.NAND, ca, cb))
+            ok &= np.array_equal(out[1], o.eval_bingate(bce.OR, ca, cb))
+            ok &= np.array_equal(out[2], o.eval_bingate(bce.AND, o.eval_not(ca), cb))
+        results[tag] = bool(ok)
+
+    ts = [threading.Thread(target=worker, args=("t%d" % i, 1000 + i)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert results == {"t0": True, "t1": True, "t2": True}
