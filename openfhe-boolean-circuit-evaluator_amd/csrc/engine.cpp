@@ -213,6 +213,9 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
             P.I4s[k] = c->is64 ? 0 : (u32)(((u128)v << 32) / Q);
             v = mul_mod(v, I, Q);
         }
+        const u64 wl = mul_mod(P.I4[3], ninv, Q);  // -I * N^-1 (I^3 = -I)
+        P.Winv_last = (u32)wl;
+        P.Winv_last_s = c->is64 ? 0 : (u32)(((u128)wl << 32) / Q);
     }
     P.tw_f = c->d_twf;
     P.psi_tab = c->d_psi;

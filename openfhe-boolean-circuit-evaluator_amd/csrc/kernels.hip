@@ -20,6 +20,8 @@
 // in LDS with 4 pad words per 64 so that all three access patterns are bank-conflict free.
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "kernels.hpp"
 
 namespace bce {
@@ -207,31 +209,106 @@ __device__ __forceinline__ void load_pass_pair(const u32* poly, u32 lane, u64 (&
 #pragma unroll
     for (int r = 0; r < Cfg<LOGN>::E; ++r) x[r] = pair_of(poly[phys(elem_j<LOGN, LO>(lane, r))]);
 }
+// Lane-major hand-off layout between the digit decomposition and the first forward pass: both
+// hold coefficient (r << 6) | lane in register r, so the layout in between is private to them.
+// Word k*256 + lane*4 + e holds register 4k + e: 16-byte accesses, consecutive lanes contiguous
+// (measured on gfx950: ds_write_b128 12.5 vs 4 x ds_write_b32 16 cycles per KiB, ds_read_b128 4.1
+// vs 4 x ds_read_b32 9.2; tools/lds_shapes.hip).
+__device__ __forceinline__ u32 lm_word(u32 lane, int k) { return (u32)k * 256u + lane * 4u; }
+template <int LOGN>
+__device__ __forceinline__ void load_lm(const u32* poly, u32 lane, u32 (&x)[Cfg<LOGN>::E]) {
+#pragma unroll
+    for (int k = 0; k < Cfg<LOGN>::E / 4; ++k) {
+        const uint4 v = *reinterpret_cast<const uint4*>(poly + lm_word(lane, k));
+        x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
+    }
+}
+template <int LOGN>
+__device__ __forceinline__ void load_lm_pair(const u32* poly, u32 lane, u64 (&x)[Cfg<LOGN>::E]) {
+#pragma unroll
+    for (int k = 0; k < Cfg<LOGN>::E / 4; ++k) {
+        const uint4 v = *reinterpret_cast<const uint4*>(poly + lm_word(lane, k));
+        x[4 * k] = pair_of(v.x); x[4 * k + 1] = pair_of(v.y); x[4 * k + 2] = pair_of(v.z); x[4 * k + 3] = pair_of(v.w);
+    }
+}
 template <int LOGN, int LO>
 __device__ __forceinline__ void store_pass_pair(u32* poly, u32 lane, const u64 (&x)[Cfg<LOGN>::E]) {
 #pragma unroll
     for (int r = 0; r < Cfg<LOGN>::E; ++r) poly[phys(elem_j<LOGN, LO>(lane, r))] = (u32)x[r];
 }
 
-// Gentleman-Sande stage on bit B; values stay in [0, 2Q).  Inverse twiddles come from the
+// Gentleman-Sande stages with COMPILE-TIME BOUND TRACKING.  Inverse twiddles come from the
 // FORWARD table: psi^-k = -psi^(N-k), i.e. itw[m+i] = Q - tw[m + (m-1-i)], and the Shoup
 // companion of Q - w is the bitwise complement of w's (Q is prime, so w*2^32/Q is never integral).
-template <int LOGN, int LO, int B>
-__device__ __forceinline__ void inv_stage(u32 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q) {
-    constexpr int LE = Cfg<LOGN>::LE, E = Cfg<LOGN>::E;
-    constexpr int rb = B - LO;
-    constexpr u32 m = 1u << (LOGN - 1 - B);
-    const u32 hi = (lane >> LO) << (LO + LE - B - 1);
-    const u32 Q2 = 2 * Q;
-#pragma unroll
-    for (int r = 0; r < E; ++r) {
-        if (r & (1 << rb)) continue;
-        const uint2 f = tw[tw_pos<m>((m - 1) - (hi | (u32)(r >> (rb + 1))))];
-        const uint2 w = make_uint2(Q - f.x, ~f.y);
-        u32 X = x[r], Y = x[r | (1 << rb)];
-        x[r] = csub(X + Y, Q2);
-        x[r | (1 << rb)] = mul_shoup_lazy3(X + Q2 - Y, w, Q);
+//
+// A butterfly is X' = X + Y, Y' = (X + bQ - Y) * w with Y < bQ.  The Shoup product accepts any
+// 32-bit operand and returns [0, 2Q), so only the SUM side grows: a register that takes the sum
+// side t times in a row holds < 2^(t+1) Q.  Inside a register pass the side every register takes
+// at every stage is a compile-time fact (the stage bit is a bit of the register index), so the
+// per-stage conditional subtraction is dropped and each register is reduced once, at the end of
+// the pass, by the cheapest step its own bound needs.  Bounds are capped at GS_CAP*Q = 16Q < 2^32
+// (Q < 2^28): a stage whose sum would exceed the cap first halves its two inputs.
+// gs_bound: bound (units of Q) of register r before the stage on register bit rb, in a pass whose
+// first stage is on register bit rb0 and whose inputs are < 2Q.
+constexpr int GS_CAP = 16;
+constexpr int gs_bound(int r, int rb0, int rb) {
+    int b = 2;
+    for (int s = rb0; s < rb; ++s) {
+        if ((r >> s) & 1) b = 2;
+        else b = (2 * b > GS_CAP) ? b : 2 * b;  // capped stages first halve their inputs (see inv_bfly)
     }
+    return b;
+}
+
+template <int LOGN, int LO, int B, int RB0, bool LAST, int R>
+__device__ __forceinline__ void inv_bfly(u32 (&x)[Cfg<LOGN>::E], u32 hi, const uint2* tw, u32 Q, uint2 ninv, uint2 wlast) {
+    constexpr int rb = B - LO;
+    if constexpr ((R & (1 << rb)) == 0) {
+        constexpr u32 m = 1u << (LOGN - 1 - B);
+        constexpr int S = R | (1 << rb);
+        constexpr int b0 = gs_bound(R, RB0, rb);
+        constexpr bool cap = 2 * b0 > GS_CAP;
+        constexpr u32 b = cap ? b0 / 2 : b0;
+        u32 X = x[R], Y = x[S];
+        if constexpr (cap) { X = csub(X, b * Q); Y = csub(Y, b * Q); }
+        if constexpr (LAST) {
+            // stage LOGN-1 has the single twiddle -I: N^-1 is folded into both outputs
+            x[R] = csub(mul_shoup_lazy3(X + Y, ninv, Q), Q);
+            x[S] = csub(mul_shoup_lazy3(X + b * Q - Y, wlast, Q), Q);
+        } else {
+            const uint2 f = tw[tw_pos<m>((m - 1) - (hi | (u32)(R >> (rb + 1))))];
+            const uint2 w = make_uint2(Q - f.x, ~f.y);
+            x[R] = X + Y;
+            x[S] = mul_shoup_lazy3(X + b * Q - Y, w, Q);
+        }
+    }
+}
+template <int LOGN, int LO, int B, int RB0, bool LAST, int... R>
+__device__ __forceinline__ void inv_stage_seq(u32 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q, uint2 ninv,
+                                              uint2 wlast, std::integer_sequence<int, R...>) {
+    constexpr int LE = Cfg<LOGN>::LE;
+    const u32 hi = (lane >> LO) << (LO + LE - B - 1);
+    (inv_bfly<LOGN, LO, B, RB0, LAST, R>(x, hi, tw, Q, ninv, wlast), ...);
+}
+// stages BLO..BHI of one register pass (LASTPASS: BHI = LOGN-1 carries the N^-1 scaling)
+template <int LOGN, int LO, int BLO, int BHI, int RB0, bool LASTPASS>
+__device__ __forceinline__ void inv_stages(u32 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q, uint2 ninv, uint2 wlast) {
+    if constexpr (BLO <= BHI) {
+        inv_stage_seq<LOGN, LO, BLO, RB0, (LASTPASS && BLO == BHI)>(x, lane, tw, Q, ninv, wlast,
+                                                                   std::make_integer_sequence<int, Cfg<LOGN>::E>{});
+        inv_stages<LOGN, LO, BLO + 1, BHI, RB0, LASTPASS>(x, lane, tw, Q, ninv, wlast);
+    }
+}
+// end of a (non-final) pass: every register back below 2Q
+template <int LOGN, int RB0, int RBEND, int... R>
+__device__ __forceinline__ void inv_pass_reduce(u32 (&x)[Cfg<LOGN>::E], u32 Q, u32 mu32, std::integer_sequence<int, R...>) {
+    auto red = [&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        constexpr int b = gs_bound(r, RB0, RBEND);
+        if constexpr (b == 4) x[r] = csub(x[r], 2 * Q);
+        else if constexpr (b > 4) x[r] = x[r] - __umulhi(x[r], mu32) * Q;  // any 32-bit value -> [0, 2Q)
+    };
+    (red(std::integral_constant<int, R>{}), ...);
 }
 
 template <int LOGN, int LO, int BHI, int BLO, bool LAZY>
@@ -241,26 +318,20 @@ __device__ __forceinline__ void fwd_stages(u32 (&x)[Cfg<LOGN>::E], u32 lane, con
         fwd_stages<LOGN, LO, BHI - 1, BLO, LAZY>(x, lane, tw, Q);
     }
 }
-template <int LOGN, int LO, int BLO, int BHI>
-__device__ __forceinline__ void inv_stages(u32 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q) {
-    if constexpr (BLO <= BHI) {
-        inv_stage<LOGN, LO, BLO>(x, lane, tw, Q);
-        inv_stages<LOGN, LO, BLO + 1, BHI>(x, lane, tw, Q);
-    }
-}
-
 // Forward negacyclic NTT of one polynomial by one wave, in place in LDS.
 // Input: natural order, values < 2Q (LAZY) or < 4Q.  Output: bit-reversed order, values in [0, Q)
 // (or merely < (2*LOGN+2)*Q when LAZY && !NORM).
 // mu32 = floor(2^32 / Q) (LAZY only).
-template <int LOGN, bool LAZY, bool NORM = true>
+// LM_IN: the input sits in the lane-major hand-off layout (lm_word) instead of the padded natural one.
+template <int LOGN, bool LAZY, bool NORM = true, bool LM_IN = false>
 __device__ __forceinline__ void ntt_forward_wave(u32* poly, const uint2* twf, u32 lane, u32 Q, u32 mu32) {
     using C = Cfg<LOGN>;
     u32 x[C::E];
     if constexpr (LAZY && C::F2LO > 0) {
         // passes 1 and 2 on register pairs (5-instruction butterflies), pass 3 on plain registers
         u64 xp[C::E];
-        load_pass_pair<LOGN, 6>(poly, lane, xp);
+        if constexpr (LM_IN) load_lm_pair<LOGN>(poly, lane, xp);
+        else load_pass_pair<LOGN, 6>(poly, lane, xp);
         fwd_stages_pair<LOGN, 6, LOGN - 1, 6>(xp, lane, twf, Q);
         store_pass_pair<LOGN, 6>(poly, lane, xp);
         wave_sync();
@@ -271,7 +342,8 @@ __device__ __forceinline__ void ntt_forward_wave(u32* poly, const uint2* twf, u3
         load_pass<LOGN, 0>(poly, lane, x);
         fwd_stages<LOGN, 0, C::F2LO - 1, 0, LAZY>(x, lane, twf, Q);
     } else {
-        load_pass<LOGN, 6>(poly, lane, x);
+        if constexpr (LM_IN) load_lm<LOGN>(poly, lane, x);
+        else load_pass<LOGN, 6>(poly, lane, x);
         fwd_stages<LOGN, 6, LOGN - 1, 6, LAZY>(x, lane, twf, Q);
         store_pass<LOGN, 6>(poly, lane, x);
         wave_sync();
@@ -302,23 +374,26 @@ __device__ __forceinline__ void ntt_forward_wave(u32* poly, const uint2* twf, u3
 
 // Inverse NTT by one wave: reads `src` (bit-reversed order, values < 2Q), uses `tmp` for the
 // re-shuffles (may alias src), leaves coefficient j = (r << 6) | lane in x[r], in [0, Q).
+// ninv = N^-1, wlast = -I * N^-1 (I = psi^(N/2)), both with Shoup companions; mu32 = floor(2^32 / Q).
 template <int LOGN>
 __device__ __forceinline__ void ntt_inverse_wave(const u32* src, u32* tmp, const uint2* twi, u32 lane, u32 Q,
-                                                 uint2 ninv, u32 (&x)[Cfg<LOGN>::E]) {
+                                                 uint2 ninv, uint2 wlast, u32 mu32, u32 (&x)[Cfg<LOGN>::E]) {
     using C = Cfg<LOGN>;
     constexpr int LE = C::LE;
+    constexpr auto regs = std::make_integer_sequence<int, C::E>{};
     load_pass<LOGN, 0>(src, lane, x);
-    inv_stages<LOGN, 0, 0, LE - 1>(x, lane, twi, Q);
+    inv_stages<LOGN, 0, 0, LE - 1, 0, false>(x, lane, twi, Q, ninv, wlast);
+    inv_pass_reduce<LOGN, 0, LE>(x, Q, mu32, regs);
     store_pass<LOGN, 0>(tmp, lane, x);
     wave_sync();
     load_pass<LOGN, LE>(tmp, lane, x);
-    inv_stages<LOGN, LE, LE, 2 * LE - 1>(x, lane, twi, Q);
+    inv_stages<LOGN, LE, LE, 2 * LE - 1, 0, false>(x, lane, twi, Q, ninv, wlast);
+    inv_pass_reduce<LOGN, 0, LE>(x, Q, mu32, regs);
     store_pass<LOGN, LE>(tmp, lane, x);
     wave_sync();
     load_pass<LOGN, 6>(tmp, lane, x);
-    inv_stages<LOGN, 6, 2 * LE, LOGN - 1>(x, lane, twi, Q);
-#pragma unroll
-    for (int r = 0; r < C::E; ++r) x[r] = csub(mul_shoup_lazy3(x[r], ninv, Q), Q);
+    inv_stages<LOGN, 6, 2 * LE, LOGN - 1, 2 * LE - 6, true>(x, lane, twi, Q, ninv, wlast);
+    // every register is an output of the last stage: scaled by N^-1 and in [0, Q)
 }
 
 // psi^e for e in [0, 2N) from the forward table (tw_f[brv(i)] = psi^i, psi^(i+N) = -psi^i)
@@ -416,7 +491,7 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
     if (wave == 0) ntt_forward_wave<LOGN, LAZY>(acc + NP, twf, lane, Q, P.mu32);
     __syncthreads();
 
-    const uint2 ninv = make_uint2(P.Ninv, P.Ninv_s);
+    const uint2 ninv = make_uint2(P.Ninv, P.Ninv_s), wlast = make_uint2(P.Winv_last, P.Winv_last_s);
     constexpr u32 rgsw = R * 2 * N;  // words per RGSW ciphertext
     // GINX key = n * 2 * rgsw words < 4 GiB: one buffer resource covers it (raw, no stride, bounds-checked)
     const __amdgpu_buffer_rsrc_t rsrc =
@@ -443,24 +518,49 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
         // (1) two waves: INTT of acc[c], SignedDigitDecompose -> dct[2l + c] (coefficient form)
         if (wave < 2) {
             u32 x[E];
-            ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, twf, lane, Q, ninv, x);
+            ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, twf, lane, Q, ninv, wlast, P.mu32, x);
             const u32 Qh = Q >> 1;
+            if constexpr (LAZY) {
+                // SignedDigitDecompose in closed form.  The balanced digits r_l in [-B/2, B/2) of
+                // d = sum r_l B^l are unique mod B^dG, and d + sum (B/2) B^l = sum (r_l + B/2) B^l has the
+                // plain digits r_l + B/2: one v_bfe_u32 per digit instead of the extract/subtract/shift
+                // chain.  rem + Q (in (Q - B/2, Q + B/2)) is as good an input as rem mod Q for the lazy NTT.
+                const u32 g = P.gBits;
+                u32 off = 0;
+                for (u32 l = 0; l < (u32)DG; ++l) off |= 1u << (l * g + g - 1);
+                const u32 offm = off - Q, bias = Q - (1u << (g - 1));
 #pragma unroll
-            for (int r = 0; r < E; ++r) {
-                int d = (x[r] < Qh) ? (int)x[r] : (int)x[r] - (int)Q;
-                const u32 pj = phys(((u32)r << 6) | lane);
+                for (int k = 0; k < E / 4; ++k) {
+                    u32 u[4];
 #pragma unroll
-                for (u32 l = 0; l < (u32)DG; ++l) {
-                    int rem = __builtin_amdgcn_sbfe(d, 0, P.gBits);  // signed digit in [-B/2, B/2): v_bfe_i32
-                    d = (d - rem) >> P.gBits;
-                    // LAZY: rem + Q (in (Q-B/2, Q+B/2)) is as good an input as rem mod Q for the lazy NTT
-                    dct[(2 * l + wave) * NP + pj] = LAZY ? (u32)(rem + (int)Q) : (rem < 0 ? (u32)(rem + (int)Q) : (u32)rem);
+                    for (int e = 0; e < 4; ++e) u[e] = x[4 * k + e] + ((x[4 * k + e] < Qh) ? off : offm);
+#pragma unroll
+                    for (u32 l = 0; l < (u32)DG; ++l) {
+                        uint4 v;
+                        v.x = __builtin_amdgcn_ubfe(u[0], l * g, g) + bias;
+                        v.y = __builtin_amdgcn_ubfe(u[1], l * g, g) + bias;
+                        v.z = __builtin_amdgcn_ubfe(u[2], l * g, g) + bias;
+                        v.w = __builtin_amdgcn_ubfe(u[3], l * g, g) + bias;
+                        *reinterpret_cast<uint4*>(dct + (2 * l + wave) * NP + lm_word(lane, k)) = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    int d = (x[r] < Qh) ? (int)x[r] : (int)x[r] - (int)Q;
+                    const u32 pj = phys(((u32)r << 6) | lane);
+#pragma unroll
+                    for (u32 l = 0; l < (u32)DG; ++l) {
+                        int rem = __builtin_amdgcn_sbfe(d, 0, P.gBits);  // signed digit in [-B/2, B/2): v_bfe_i32
+                        d = (d - rem) >> P.gBits;
+                        dct[(2 * l + wave) * NP + pj] = rem < 0 ? (u32)(rem + (int)Q) : (u32)rem;
+                    }
                 }
             }
         }
         __syncthreads();
         // (2) one wave per decomposed polynomial: forward NTT in place
-        ntt_forward_wave<LOGN, LAZY, false>(dct + wave * NP, twf, lane, Q, P.mu32);
+        ntt_forward_wave<LOGN, LAZY, false, LAZY>(dct + wave * NP, twf, lane, Q, P.mu32);
         __syncthreads();
         // (3) RGSW multiply-accumulate
         if constexpr (AP) {
@@ -584,7 +684,7 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
     // accumulator back to COEFFICIENT form for the extraction kernel
     if (wave < 2) {
         u32 x[E];
-        ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, twf, lane, Q, ninv, x);
+        ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, twf, lane, Q, ninv, wlast, P.mu32, x);
         u32* out = acc_out + ((size_t)blockIdx.x * 2 + wave) * N;
 #pragma unroll
         for (int r = 0; r < E; ++r) out[((u32)r << 6) | lane] = x[r];
@@ -793,7 +893,8 @@ __global__ __launch_bounds__(256) void k_ntt_batch(DevParams P, u32* __restrict_
             }
         } else {
             u32 x[E];
-            ntt_inverse_wave<LOGN>(mine, mine, tw, lane, P.Q, make_uint2(P.Ninv, P.Ninv_s), x);
+            ntt_inverse_wave<LOGN>(mine, mine, tw, lane, P.Q, make_uint2(P.Ninv, P.Ninv_s),
+                                   make_uint2(P.Winv_last, P.Winv_last_s), P.mu32, x);
 #pragma unroll
             for (int r = 0; r < E; ++r) gp[((u32)r << 6) | lane] = x[r];
         }

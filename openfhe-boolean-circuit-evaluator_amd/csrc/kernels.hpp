@@ -28,7 +28,8 @@ struct DevParams {
     u32 red_shift;    // Barrett for x < 2^(2*bitlen(Q)+3): x1 = x >> red_shift
     u32 red_mu;       // floor(2^(32+red_shift) / Q)
     u32 Ninv, Ninv_s; // N^-1 mod Q and its Shoup companion
-    u32 mu32;         // floor(2^32 / Q): final reduction of the lazy forward NTT
+    u32 Winv_last, Winv_last_s;  // -psi^(N/2) * N^-1: twiddle of the last inverse stage with the scaling folded in
+    u32 mu32;         // floor(2^32 / Q): one-step reduction of any 32-bit value to [0, 2Q)
     u32 lazy;         // 1 when the forward NTT can run without any correction (bounds in engine.cpp)
     u32 c32;          // 2^32 mod Q (folds 64-bit MAC sums of un-normalised NTT outputs)
     u32 occupancy_target;  // workgroups per CU the blind-rotation kernel is compiled for (2 or 3)
