@@ -58,8 +58,12 @@ __device__ __forceinline__ u32 mul_shoup_lazy3(u32 y, uint2 w, u32 Q) {
     return (u32)mad64(__umulhi(w.y, y), 0u - Q, mul64(y, w.x));
 }
 __device__ __forceinline__ u64 pair_of(u32 lo) {
-    u32 junk = __builtin_nondeterministic_value(junk);
-    return ((u64)junk << 32) | lo;
+    // an empty asm "defines" a fresh register pair without any instruction; only its low half is then
+    // written, so the producer of `lo` can target that half directly (a frozen don't-care value would
+    // have to be COPIED into every pair's high half instead)
+    u64 p;
+    asm volatile("" : "=v"(p));
+    return (p & 0xFFFFFFFF00000000ull) | lo;
 }
 __device__ __forceinline__ u64 with_lo(u64 pair, u32 lo) { return (pair & 0xFFFFFFFF00000000ull) | lo; }
 
@@ -197,6 +201,22 @@ __device__ __forceinline__ void fwd_stage_pair(u64 (&x)[Cfg<LOGN>::E], u32 lane,
         x[r] = t;
     }
 }
+// First stage (bit LOGN-1, one twiddle) straight from PLAIN registers into pairs: only the X operands are
+// needed as 64-bit addends, the Y' results are born in pair low halves -- no register-pair set-up moves
+// for the 16-byte loads of the lane-major hand-off.
+template <int LOGN>
+__device__ __forceinline__ void fwd_first_stage_pair(const u32 (&x)[Cfg<LOGN>::E], u64 (&xp)[Cfg<LOGN>::E], const uint2* tw, u32 Q) {
+    constexpr int E = Cfg<LOGN>::E, Hh = E / 2;
+    const u32 Q2 = 2 * Q, negQ = 0u - Q;
+    const uint2 w = tw[1];
+#pragma unroll
+    for (int r = 0; r < Hh; ++r) {
+        const u32 X = x[r], Y = x[r + Hh];
+        const u64 t = mad64(__umulhi(Y, w.y), negQ, mad64(Y, w.x, pair_of(X)));
+        xp[r] = t;
+        xp[r + Hh] = pair_of((X << 1) + Q2 - (u32)t);
+    }
+}
 template <int LOGN, int LO, int BHI, int BLO>
 __device__ __forceinline__ void fwd_stages_pair(u64 (&x)[Cfg<LOGN>::E], u32 lane, const uint2* tw, u32 Q) {
     if constexpr (BHI >= BLO) {
@@ -223,14 +243,6 @@ __device__ __forceinline__ void load_lm(const u32* poly, u32 lane, u32 (&x)[Cfg<
         x[4 * k] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
     }
 }
-template <int LOGN>
-__device__ __forceinline__ void load_lm_pair(const u32* poly, u32 lane, u64 (&x)[Cfg<LOGN>::E]) {
-#pragma unroll
-    for (int k = 0; k < Cfg<LOGN>::E / 4; ++k) {
-        const uint4 v = *reinterpret_cast<const uint4*>(poly + lm_word(lane, k));
-        x[4 * k] = pair_of(v.x); x[4 * k + 1] = pair_of(v.y); x[4 * k + 2] = pair_of(v.z); x[4 * k + 3] = pair_of(v.w);
-    }
-}
 template <int LOGN, int LO>
 __device__ __forceinline__ void store_pass_pair(u32* poly, u32 lane, const u64 (&x)[Cfg<LOGN>::E]) {
 #pragma unroll
@@ -238,10 +250,10 @@ __device__ __forceinline__ void store_pass_pair(u32* poly, u32 lane, const u64 (
 }
 
 // Gentleman-Sande stages with COMPILE-TIME BOUND TRACKING.  Inverse twiddles come from the
-// FORWARD table: psi^-k = -psi^(N-k), i.e. itw[m+i] = Q - tw[m + (m-1-i)], and the Shoup
-// companion of Q - w is the bitwise complement of w's (Q is prime, so w*2^32/Q is never integral).
+// FORWARD table: psi^-k = -psi^(N-k), i.e. itw[m+i] = -tw[m + (m-1-i)]; the sign goes into the
+// operand, so no inverse table and no per-twiddle negation is needed.
 //
-// A butterfly is X' = X + Y, Y' = (X + bQ - Y) * w with Y < bQ.  The Shoup product accepts any
+// A butterfly is X' = X + Y, Y' = (X - Y) * w = (Y + bQ - X) * (-w) with X, Y < bQ.  The Shoup product accepts any
 // 32-bit operand and returns [0, 2Q), so only the SUM side grows: a register that takes the sum
 // side t times in a row holds < 2^(t+1) Q.  Inside a register pass the side every register takes
 // at every stage is a compile-time fact (the stage bit is a bit of the register index), so the
@@ -276,10 +288,10 @@ __device__ __forceinline__ void inv_bfly(u32 (&x)[Cfg<LOGN>::E], u32 hi, const u
             x[R] = csub(mul_shoup_lazy3(X + Y, ninv, Q), Q);
             x[S] = csub(mul_shoup_lazy3(X + b * Q - Y, wlast, Q), Q);
         } else {
+            // (X - Y) * (-f) = (Y - X) * f: the forward entry is used as it is, the OPERAND is negated
             const uint2 f = tw[tw_pos<m>((m - 1) - (hi | (u32)(R >> (rb + 1))))];
-            const uint2 w = make_uint2(Q - f.x, ~f.y);
             x[R] = X + Y;
-            x[S] = mul_shoup_lazy3(X + b * Q - Y, w, Q);
+            x[S] = mul_shoup_lazy3(Y + b * Q - X, f, Q);
         }
     }
 }
@@ -330,9 +342,14 @@ __device__ __forceinline__ void ntt_forward_wave(u32* poly, const uint2* twf, u3
     if constexpr (LAZY && C::F2LO > 0) {
         // passes 1 and 2 on register pairs (5-instruction butterflies), pass 3 on plain registers
         u64 xp[C::E];
-        if constexpr (LM_IN) load_lm_pair<LOGN>(poly, lane, xp);
-        else load_pass_pair<LOGN, 6>(poly, lane, xp);
-        fwd_stages_pair<LOGN, 6, LOGN - 1, 6>(xp, lane, twf, Q);
+        if constexpr (LM_IN) {
+            load_lm<LOGN>(poly, lane, x);
+            fwd_first_stage_pair<LOGN>(x, xp, twf, Q);
+            fwd_stages_pair<LOGN, 6, LOGN - 2, 6>(xp, lane, twf, Q);
+        } else {
+            load_pass_pair<LOGN, 6>(poly, lane, xp);
+            fwd_stages_pair<LOGN, 6, LOGN - 1, 6>(xp, lane, twf, Q);
+        }
         store_pass_pair<LOGN, 6>(poly, lane, xp);
         wave_sync();
         load_pass_pair<LOGN, C::F2LO>(poly, lane, xp);

@@ -1,0 +1,50 @@
+"""Per-phase cycle split of a blind-rotation step (development aid, GPU box only).
+
+Rebuilds libbce_amd.so IN THE SCRATCH COPY with -DBCE_PHASE_PROF (the committed build never defines
+it), runs batched STD128_OPT/GINX NAND bootstraps and prints, for workgroup 0, the cycles its thread 0
+spent in each barrier-delimited phase.  Usage: python tools/phase_prof.py [batch ...]
+"""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+env = dict(os.environ, BCE_EXTRA_FLAGS="-DBCE_PHASE_PROF")
+subprocess.check_call([sys.executable, os.path.join(ROOT, "openfhe-boolean-circuit-evaluator_amd", "build.py"), "--force"],
+                      env=env, stdout=subprocess.DEVNULL)
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+bce = importlib.import_module("openfhe-boolean-circuit-evaluator_amd")
+lib = C.CDLL(bce.LIB_PATH)
+NAMES = ["own inverse NTT+digits", "wait barrier 1", "forward NTT", "wait barrier 2", "RGSW MAC", "wait barrier 3"]
+
+
+def main():
+    batches = [int(x) for x in sys.argv[1:]] or [1, 768, 2048]
+    c = bce.BinFHEContext(bce.STD128_OPT, bce.GINX)
+    c.KeyGen(42)
+    nmax = max(batches)
+    c.pool_reserve(3 * nmax)
+    bits = np.random.default_rng(0).integers(0, 2, size=2 * nmax).astype(np.uint8)
+    c.Encrypt(bits, np.arange(2 * nmax), enc_index_base=0)
+    out = (C.c_ulonglong * 8)()
+    for nb in batches:
+        descs = bce.make_descs([(bce.NAND, 2 * i, 2 * i + 1, 2 * nmax + i) for i in range(nb)])
+        c.EvalGates(descs)
+        c.synchronize()
+        lib.bce_debug_phase_prof(out, 1)
+        c.timing_reset()
+        c.EvalGates(descs)
+        c.synchronize()
+        lib.bce_debug_phase_prof(out, 1)
+        t = c.timing()
+        tot = float(sum(out[:6]))
+        print("batch %d: blind_rotate %.2f ms, workgroup 0 total %.0f cycles" % (nb, t["blind_rotate_ms"], tot))
+        for k, name in enumerate(NAMES):
+            print("   %-24s %10d cycles  %5.1f%%" % (name, out[k], 100.0 * out[k] / tot))
+
+
+main()
