@@ -205,6 +205,11 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         P.occupancy_target = (occ && occ[0] == '2') ? 2 : 3;
         const size_t lds = (2 * (size_t)N + (2 + 2 * c->dG) * ((size_t)N + (N >> 6) * 4) + ((n + 1 + 3) & ~3u)) * 4;
         if (3 * lds > 160 * 1024) P.occupancy_target = 2;
+        const char* var = std::getenv("BCE_VARIANT");  // development knob, see DevParams::variant
+        P.variant = var ? (u32)std::atoi(var) : 0;
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        P.cu_count = (u32)cus;
     }
     {
         u64 I = pow_mod(c->psi, N / 2, Q), v = 1;

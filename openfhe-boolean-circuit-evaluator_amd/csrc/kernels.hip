@@ -26,6 +26,24 @@
 
 namespace bce {
 
+// Development aid (never defined in the shipped build): -DBCE_PHASE_PROF accumulates, for workgroup 0,
+// the cycles between the barriers of a blind-rotation step; read back with bce_debug_phase_prof().
+#ifdef BCE_PHASE_PROF
+__device__ unsigned long long g_phase_prof[8];
+#define BCE_PROF_INIT() unsigned long long prof_t_ = __builtin_readcyclecounter()
+#define BCE_PROF_MARK(slot)                                                         \
+    do {                                                                            \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                  \
+            const unsigned long long now_ = __builtin_readcyclecounter();           \
+            g_phase_prof[slot] += now_ - prof_t_;                                   \
+            prof_t_ = now_;                                                         \
+        }                                                                           \
+    } while (0)
+#else
+#define BCE_PROF_INIT() do {} while (0)
+#define BCE_PROF_MARK(slot) do {} while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------
 // modular arithmetic
 // ---------------------------------------------------------------------------------------
@@ -114,6 +132,12 @@ __device__ __forceinline__ u32 tw_pos(u32 i) {
         constexpr u32 sh = __builtin_ctz(M) - 6;
         return M + ((i & ((1u << sh) - 1u)) << 6) + (i >> sh);
     }
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains outstanding GLOBAL loads
+// (s_waitcnt vmcnt(0)), which would serialise key rows requested ahead of their use.
+__device__ __forceinline__ void block_sync_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -441,34 +465,55 @@ __device__ __forceinline__ u32 gate_const(u32 op, u32 q) {
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// blind rotation (GINX / CGGI): one workgroup = one gate bootstrap, one wave per RGSW row
-// ---------------------------------------------------------------------------------------
-// OCC = workgroups the register budget is sized for per CU (2 or 3); LDS per workgroup is
-// 8 KiB twiddles + (2 + 2*DG) padded polynomials + ctprep = 52.5 KiB at N = 1024, DG = 4.
-// AP = false: GINX/CGGI AddToAcc (two RGSW keys per LWE coefficient, monomial multiply, accumulate);
-// AP = true : AP/DM AddToAcc (one RGSW key per base-baseR digit of -a_i, acc is replaced).
-template <int LOGN, int DG, bool LAZY, int OCC, bool AP>
-__global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rotate(
-    DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc, u32 slot_stride, u32* __restrict__ acc_out) {
+// Tail of one GINX MAC item: sp / sn are the 64-bit row sums against key+ / key- at the 4 consecutive
+// evaluation positions p0..p0+3; multiplies them by the monomials psi^(+-(2k+1)a') - 1 and accumulates
+// into the 4 accumulator words at accp.
+// I^a' and I^-a' for I = psi^(N/2): the 4 positions sit at evaluation points whose exponents differ by
+// multiples of (N/2)*a' (brv(p0+e) = brv(p0) + {0,2,1,3}*N/4).
+template <int LOGN, bool LAZY>
+__device__ __forceinline__ void ginx_mac_tail(const DevParams& P, __amdgpu_buffer_rsrc_t psi_rsrc, u32 Q, u32 ap, uint2 Ia,
+                                              uint2 Ina, u32 p0, u32* accp, const u64 (&sp)[4], const u64 (&sn)[4]) {
+    constexpr u32 N = 1u << LOGN;
+    const bool odd = ap & 1u;
+    const u32 k0 = __brev(p0) >> (32 - LOGN);
+    const u32 ex = ((2 * k0 + 1) * ap) & (2 * N - 1);
+    u32 mp[4], mn[4];
+    mp[0] = psi_pow<LOGN>(psi_rsrc, ex, Q);
+    mn[0] = psi_pow<LOGN>(psi_rsrc, (2 * N - ex) & (2 * N - 1), Q);
+    mp[2] = csub(mul_shoup_lazy(mp[0], Ia, Q), Q);
+    mn[2] = csub(mul_shoup_lazy(mn[0], Ina, Q), Q);
+    mp[1] = odd ? Q - mp[0] : mp[0];
+    mn[1] = odd ? Q - mn[0] : mn[0];
+    mp[3] = odd ? Q - mp[2] : mp[2];
+    mn[3] = odd ? Q - mn[2] : mn[2];
+    uint4 a4v = *reinterpret_cast<const uint4*>(accp);
+    u32 a[4] = {a4v.x, a4v.y, a4v.z, a4v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if constexpr (LAZY) {
+            // fold the high word (sum < 2^62), reduce lazily to [0,3Q); the three-term sum
+            // 3Q*Q + 3Q*Q + 2Q stays below the 2^(32+shift) Barrett bound; acc is kept in [0,2Q)
+            const u32 rp = barrett_lazy3((u64)(u32)(sp[e] >> 32) * P.c32 + (u32)sp[e], Q, P.red_shift, P.red_mu);
+            const u32 rn = barrett_lazy3((u64)(u32)(sn[e] >> 32) * P.c32 + (u32)sn[e], Q, P.red_shift, P.red_mu);
+            a[e] = csub(barrett_lazy3((u64)rp * (mp[e] - 1) + (u64)rn * (mn[e] - 1) + a[e], Q, P.red_shift, P.red_mu), 2 * Q);
+        } else {
+            const u32 rp = barrett_reduce(sp[e], Q, P.red_shift, P.red_mu);
+            const u32 rn = barrett_reduce(sn[e], Q, P.red_shift, P.red_mu);
+            a[e] = barrett_reduce((u64)rp * (mp[e] - 1) + (u64)rn * (mn[e] - 1) + a[e], Q, P.red_shift, P.red_mu);
+        }
+    }
+    *reinterpret_cast<uint4*>(accp) = make_uint4(a[0], a[1], a[2], a[3]);
+}
+
+// Common start of a gate bootstrap: twiddles into LDS, EvalBinGate's LWE preparation (ct1 + ct2 with the
+// folded EvalNOTs, or ct + q/4 for a refresh) into av[0..n], BootstrapGateCore's test vector into acc
+// (evaluation form).  Ends with a workgroup barrier.
+template <int LOGN, bool LAZY, u32 T>
+__device__ __forceinline__ void bootstrap_prologue(const DevParams& P, const bce_gate_desc& g, u32 soff, uint2* twf, u32* acc,
+                                                   u32* av, u32 tid, u32 lane, u32 wave) {
     using C = Cfg<LOGN>;
-    constexpr int N = C::N, NP = C::NP, E = C::E;
-    constexpr u32 R = 2 * DG;
-    constexpr u32 T = 64 * R;
-    extern __shared__ __align__(16) u32 smem[];
-    uint2* twf = reinterpret_cast<uint2*>(smem);
-    u32* acc = reinterpret_cast<u32*>(twf + N);  // [2][NP]  EVALUATION domain, [0,Q) ([0,2Q) when LAZY)
-    u32* dct = acc + 2 * NP;                     // [R][NP]
-    u32* av = dct + R * NP;                      // ctprep: a[0..n), b
-
-    const u32 tid = threadIdx.x;
-    const u32 lane = tid & 63;
-    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keep it (and wave*NP) in SGPRs
+    constexpr int N = C::N, NP = C::NP;
     const u32 Q = P.Q, q = P.q, qm = q - 1, n = P.n;
-
-    const bce_gate_desc g = descs[blockIdx.x % n_desc];
-    const u32 soff = (blockIdx.x / n_desc) * slot_stride;
-
     for (u32 i = tid; i < (u32)N; i += T) twf[i] = P.tw_f[i];
     {   // EvalBinGate LWE prep with folded EvalNOT: (-a, q/4 - b)
         const u32* in0 = P.pool + (size_t)(g.in0 + soff) * P.pool_stride;
@@ -507,6 +552,37 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
     __syncthreads();
     if (wave == 0) ntt_forward_wave<LOGN, LAZY>(acc + NP, twf, lane, Q, P.mu32);
     __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
+// blind rotation (GINX / CGGI): one workgroup = one gate bootstrap, one wave per RGSW row
+// ---------------------------------------------------------------------------------------
+// OCC = workgroups the register budget is sized for per CU (2 or 3); LDS per workgroup is
+// 8 KiB twiddles + (2 + 2*DG) padded polynomials + ctprep = 52.5 KiB at N = 1024, DG = 4.
+// AP = false: GINX/CGGI AddToAcc (two RGSW keys per LWE coefficient, monomial multiply, accumulate);
+// AP = true : AP/DM AddToAcc (one RGSW key per base-baseR digit of -a_i, acc is replaced).
+template <int LOGN, int DG, bool LAZY, int OCC, bool AP>
+__global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rotate(
+    DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc, u32 slot_stride, u32* __restrict__ acc_out) {
+    using C = Cfg<LOGN>;
+    constexpr int N = C::N, NP = C::NP, E = C::E;
+    constexpr u32 R = 2 * DG;
+    constexpr u32 T = 64 * R;
+    extern __shared__ __align__(16) u32 smem[];
+    uint2* twf = reinterpret_cast<uint2*>(smem);
+    u32* acc = reinterpret_cast<u32*>(twf + N);  // [2][NP]  EVALUATION domain, [0,Q) ([0,2Q) when LAZY)
+    u32* dct = acc + 2 * NP;                     // [R][NP]
+    u32* av = dct + R * NP;                      // ctprep: a[0..n), b
+
+    const u32 tid = threadIdx.x;
+    const u32 lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keep it (and wave*NP) in SGPRs
+    const u32 Q = P.Q, q = P.q, qm = q - 1, n = P.n;
+
+    const bce_gate_desc g = descs[blockIdx.x % n_desc];
+    const u32 soff = (blockIdx.x / n_desc) * slot_stride;
+
+    bootstrap_prologue<LOGN, LAZY, T>(P, g, soff, twf, acc, av, tid, lane, wave);
 
     const uint2 ninv = make_uint2(P.Ninv, P.Ninv_s), wlast = make_uint2(P.Winv_last, P.Winv_last_s);
     constexpr u32 rgsw = R * 2 * N;  // words per RGSW ciphertext
@@ -516,6 +592,7 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
     const __amdgpu_buffer_rsrc_t psi_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(P.psi_tab), 0, N * 4, 0x00020000);
     // GINX: one step per LWE coefficient; AP: one step per (coefficient, base-baseR digit)
     const u32 nsteps = AP ? n * P.dR : n;
+    BCE_PROF_INIT();
     for (u32 step = 0; step < nsteps; ++step) {
         u32 ap = 0, rowb = 0;
         const u32* bk;
@@ -575,10 +652,14 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
                 }
             }
         }
+        BCE_PROF_MARK(0);  // thread 0's own phase-1 work
         __syncthreads();
+        BCE_PROF_MARK(1);
         // (2) one wave per decomposed polynomial: forward NTT in place
         ntt_forward_wave<LOGN, LAZY, false, LAZY>(dct + wave * NP, twf, lane, Q, P.mu32);
+        BCE_PROF_MARK(2);
         __syncthreads();
+        BCE_PROF_MARK(3);
         // (3) RGSW multiply-accumulate
         if constexpr (AP) {
             // acc[c] = sum_l dct[l] * ek[l][c]   (rgsw-acc-dm.cpp AddToAcc: the product REPLACES acc)
@@ -604,12 +685,9 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
             __syncthreads();
             continue;
         }
-        // I^a' and I^-a' for I = psi^(N/2): the 4 positions p0..p0+3 sit at evaluation points whose
-        // exponents differ by multiples of (N/2)*a' (brv(p0+e) = brv(p0) + {0,2,1,3}*N/4)
-        const u32 a4 = ap & 3u;
+        const u32 a4 = ap & 3u;  // I^a' and I^-a' (ginx_mac_tail)
         const uint2 Ia = make_uint2(P.I4[a4], P.I4s[a4]);
         const uint2 Ina = make_uint2(P.I4[(4u - a4) & 3u], P.I4s[(4u - a4) & 3u]);
-        const bool odd = ap & 1u;
         for (u32 item = tid; item < 2u * (N / 4); item += T) {
             const u32 c = item / (N / 4), p0 = (item % (N / 4)) * 4;
             const u32 pp = phys(p0);
@@ -665,37 +743,11 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
                 sn[0] += (u64)d.x * kA[l].x; sn[1] += (u64)d.y * kA[l].y; sn[2] += (u64)d.z * kA[l].z; sn[3] += (u64)d.w * kA[l].w;
             }
             }
-            // monomials psi^(+-(2k+1)a') - 1 at the four positions
-            const u32 k0 = __brev(p0) >> (32 - LOGN);
-            const u32 ex = ((2 * k0 + 1) * ap) & (2 * N - 1);
-            u32 mp[4], mn[4];
-            mp[0] = psi_pow<LOGN>(psi_rsrc, ex, Q);
-            mn[0] = psi_pow<LOGN>(psi_rsrc, (2 * N - ex) & (2 * N - 1), Q);
-            mp[2] = csub(mul_shoup_lazy(mp[0], Ia, Q), Q);
-            mn[2] = csub(mul_shoup_lazy(mn[0], Ina, Q), Q);
-            mp[1] = odd ? Q - mp[0] : mp[0];
-            mn[1] = odd ? Q - mn[0] : mn[0];
-            mp[3] = odd ? Q - mp[2] : mp[2];
-            mn[3] = odd ? Q - mn[2] : mn[2];
-            uint4 a4v = *reinterpret_cast<const uint4*>(acc + c * NP + pp);
-            u32 a[4] = {a4v.x, a4v.y, a4v.z, a4v.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if constexpr (LAZY) {
-                    // fold the high word (sum < 2^62), reduce lazily to [0,3Q); the three-term sum
-                    // 3Q*Q + 3Q*Q + 2Q stays below the 2^(32+shift) Barrett bound; acc is kept in [0,2Q)
-                    const u32 rp = barrett_lazy3((u64)(u32)(sp[e] >> 32) * P.c32 + (u32)sp[e], Q, P.red_shift, P.red_mu);
-                    const u32 rn = barrett_lazy3((u64)(u32)(sn[e] >> 32) * P.c32 + (u32)sn[e], Q, P.red_shift, P.red_mu);
-                    a[e] = csub(barrett_lazy3((u64)rp * (mp[e] - 1) + (u64)rn * (mn[e] - 1) + a[e], Q, P.red_shift, P.red_mu), 2 * Q);
-                } else {
-                    const u32 rp = barrett_reduce(sp[e], Q, P.red_shift, P.red_mu);
-                    const u32 rn = barrett_reduce(sn[e], Q, P.red_shift, P.red_mu);
-                    a[e] = barrett_reduce((u64)rp * (mp[e] - 1) + (u64)rn * (mn[e] - 1) + a[e], Q, P.red_shift, P.red_mu);
-                }
-            }
-            *reinterpret_cast<uint4*>(acc + c * NP + pp) = make_uint4(a[0], a[1], a[2], a[3]);
+            ginx_mac_tail<LOGN, LAZY>(P, psi_rsrc, Q, ap, Ia, Ina, p0, acc + c * NP + pp, sp, sn);
         }
+        BCE_PROF_MARK(4);
         __syncthreads();
+        BCE_PROF_MARK(5);
     }
 
     // accumulator back to COEFFICIENT form for the extraction kernel
@@ -706,6 +758,262 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
 #pragma unroll
         for (int r = 0; r < E; ++r) out[((u32)r << 6) | lane] = x[r];
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// blind rotation, LATENCY variant (GINX, N = 1024, dG = 4, lazy arithmetic)
+// ---------------------------------------------------------------------------------------
+// A wave issues at most one VALU instruction every 5-9 cycles (measured, tools/clock_probe.hip), so the
+// step time of a lone workgroup is set by how many of its waves work at once.  The throughput kernel above
+// runs the two inverse transforms of a step on two waves (41% of a lone workgroup's step time) and exposes
+// the key-row load latency twice per step.  This variant is for launches that leave CUs to themselves:
+//   * each inverse transform is split over FOUR waves: 256 threads x 4 coefficients, five 2-stage passes
+//     exchanged through two ping-pong LDS buffers whose layouts are bank-conflict free on both sides
+//     with compile-time register offsets (e0: padded natural, e1: p[3:0] + 20 p[5:4] + 80 p[7:6] + 320 p[9:8],
+//     e2: p[5:0] + 80 p[7:6] + 320 p[9:8], e3: natural);
+//   * the 15 inverse twiddles of a thread do not depend on the step: they live in registers;
+//   * all 16 key rows of a step are requested at the top of the step and the barriers inside a step
+//     order LDS only, so the L2/HBM latency hides behind the transforms (64 VGPRs of loads in flight,
+//     affordable at <= 2 workgroups per CU).
+// Results are bit-identical to the throughput kernel (same arithmetic, different schedule).
+__device__ __forceinline__ u32 xlay1(u32 p) { return (p & 15u) + 20u * ((p >> 4) & 3u) + 80u * ((p >> 6) & 3u) + 320u * (p >> 8); }
+__device__ __forceinline__ u32 xlay2(u32 p) { return (p & 63u) + 80u * ((p >> 6) & 3u) + 320u * (p >> 8); }
+
+// two Gentleman-Sande stages on 4 registers whose index is the 2-bit field (B0+1, B0) of the position:
+// stage B0 pairs (0,1) [twiddle fa] and (2,3) [fb], stage B0+1 pairs (0,2), (1,3) [fc].  In < 2Q, out < 2Q.
+__device__ __forceinline__ void inv_pass4(u32 (&x)[4], uint2 fa, uint2 fb, uint2 fc, u32 Q, u32 mu32) {
+    const u32 Q2 = 2 * Q;
+    const u32 a0 = x[0] + x[1];                                  // < 4Q
+    const u32 a1 = mul_shoup_lazy3(x[1] + Q2 - x[0], fa, Q);     // < 2Q
+    const u32 a2 = x[2] + x[3];
+    const u32 a3 = mul_shoup_lazy3(x[3] + Q2 - x[2], fb, Q);
+    const u32 b0 = a0 + a2;                                      // < 8Q
+    x[2] = mul_shoup_lazy3(a2 + 2 * Q2 - a0, fc, Q);
+    const u32 b1 = a1 + a3;                                      // < 4Q
+    x[3] = mul_shoup_lazy3(a3 + Q2 - a1, fc, Q);
+    x[0] = b0 - __umulhi(b0, mu32) * Q;                          // any 32-bit value -> [0, 2Q)
+    x[1] = csub(b1, Q2);
+}
+// the last two stages (bits 8, 9) with N^-1 folded into the final one; out in [0, Q)
+__device__ __forceinline__ void inv_pass4_last(u32 (&x)[4], uint2 fa, uint2 fb, uint2 ninv, uint2 wlast, u32 Q) {
+    const u32 Q2 = 2 * Q;
+    const u32 a0 = x[0] + x[1];
+    const u32 a1 = mul_shoup_lazy3(x[1] + Q2 - x[0], fa, Q);
+    const u32 a2 = x[2] + x[3];
+    const u32 a3 = mul_shoup_lazy3(x[3] + Q2 - x[2], fb, Q);
+    x[0] = csub(mul_shoup_lazy3(a0 + a2, ninv, Q), Q);
+    x[2] = csub(mul_shoup_lazy3(a0 + 2 * Q2 - a2, wlast, Q), Q);
+    x[1] = csub(mul_shoup_lazy3(a1 + a3, ninv, Q), Q);
+    x[3] = csub(mul_shoup_lazy3(a1 + Q2 - a3, wlast, Q), Q);
+}
+
+// per-thread, step-invariant state of the split inverse transform.  REGTW: the thread's 14 inverse twiddles stay
+// in registers for the whole bootstrap; otherwise only their table positions do and they are re-read per step.
+template <bool REGTW>
+struct SplitInv {
+    u32 a0, l1, s1, l2, s2, l3, s3, t;
+    uint2 fa[REGTW ? 5 : 1], fb[REGTW ? 5 : 1], fc[REGTW ? 4 : 1];
+    u32 ia[REGTW ? 1 : 4], ic[REGTW ? 1 : 4];  // positions of fa (fb sits at the entry with index - 1) and fc
+};
+template <bool REGTW>
+__device__ __forceinline__ void split_inv_setup(SplitInv<REGTW>& S, const uint2* twf, u32 t) {
+    S.t = t;
+    S.a0 = phys(4 * t);
+    const u32 pb1 = ((t >> 2) << 4) | (t & 3u), pb2 = ((t >> 4) << 6) | (t & 15u), pb3 = ((t >> 6) << 8) | (t & 63u);
+    S.l1 = phys(pb1); S.s1 = xlay1(pb1);
+    S.l2 = xlay1(pb2); S.s2 = xlay2(pb2);
+    S.l3 = xlay2(pb3); S.s3 = pb3;
+    // stage B (block m = 2^(9-B)) uses -tw[m + (m-1-i)], i = position >> (B+1); the sign sits in the operand
+    const u32 u0 = t, u1 = t >> 2, u2 = t >> 4, u3 = t >> 6;
+    if constexpr (REGTW) {
+        S.fa[0] = twf[tw_pos<512>(511 - 2 * u0)]; S.fb[0] = twf[tw_pos<512>(510 - 2 * u0)]; S.fc[0] = twf[tw_pos<256>(255 - u0)];
+        S.fa[1] = twf[tw_pos<128>(127 - 2 * u1)]; S.fb[1] = twf[tw_pos<128>(126 - 2 * u1)]; S.fc[1] = twf[tw_pos<64>(63 - u1)];
+        S.fa[2] = twf[tw_pos<32>(31 - 2 * u2)];   S.fb[2] = twf[tw_pos<32>(30 - 2 * u2)];   S.fc[2] = twf[tw_pos<16>(15 - u2)];
+        S.fa[3] = twf[tw_pos<8>(7 - 2 * u3)];     S.fb[3] = twf[tw_pos<8>(6 - 2 * u3)];     S.fc[3] = twf[tw_pos<4>(3 - u3)];
+        S.fa[4] = twf[tw_pos<2>(1)];              S.fb[4] = twf[tw_pos<2>(0)];
+    } else {
+        S.ia[0] = tw_pos<512>(511 - 2 * u0); S.ic[0] = tw_pos<256>(255 - u0);
+        S.ia[1] = tw_pos<128>(127 - 2 * u1); S.ic[1] = tw_pos<64>(63 - u1);
+        S.ia[2] = tw_pos<32>(31 - 2 * u2);   S.ic[2] = tw_pos<16>(15 - u2);
+        S.ia[3] = tw_pos<8>(7 - 2 * u3);     S.ic[3] = tw_pos<4>(3 - u3);
+    }
+}
+// twiddles of pass K (0..3) / of the last pass
+template <bool REGTW, int K>
+__device__ __forceinline__ void split_tw(const SplitInv<REGTW>& S, const uint2* twf, uint2& fa, uint2& fb, uint2& fc) {
+    if constexpr (REGTW) { fa = S.fa[K]; fb = S.fb[K]; fc = S.fc[K]; }
+    else {
+        constexpr u32 M = 512u >> (2 * K);
+        fa = twf[S.ia[K]];
+        // entry i-1: one position lower in natural blocks; in transposed blocks (M >= 64, i odd -> i-1 even)
+        // the low index bit is the high position bit: 64 positions lower
+        fb = twf[M < 64 ? S.ia[K] - 1 : S.ia[K] - 64];
+        fc = twf[S.ic[K]];
+    }
+}
+// src: evaluation-form polynomial (padded natural layout, values < 2Q); xa / xb: ping-pong exchange buffers
+// (1280 words each).  Leaves coefficient j = (r << 8) | t in x[r], in [0, Q).  Contains 4 workgroup barriers.
+template <bool REGTW>
+__device__ __forceinline__ void split_inverse(const SplitInv<REGTW>& S, const uint2* twf, const u32* src, u32* xa, u32* xb, u32 Q,
+                                              u32 mu32, uint2 ninv, uint2 wlast, u32 (&x)[4]) {
+    uint2 fa, fb, fc;
+    {
+        const uint4 v = *reinterpret_cast<const uint4*>(src + S.a0);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+        split_tw<REGTW, 0>(S, twf, fa, fb, fc);
+        inv_pass4(x, fa, fb, fc, Q, mu32);
+        *reinterpret_cast<uint4*>(xa + S.a0) = make_uint4(x[0], x[1], x[2], x[3]);
+    }
+    block_sync_lds();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = xa[S.l1 + 4 * r];
+    split_tw<REGTW, 1>(S, twf, fa, fb, fc);
+    inv_pass4(x, fa, fb, fc, Q, mu32);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xb[S.s1 + 4 * r] = x[r];
+    block_sync_lds();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = xb[S.l2 + 20 * r];
+    split_tw<REGTW, 2>(S, twf, fa, fb, fc);
+    inv_pass4(x, fa, fb, fc, Q, mu32);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xa[S.s2 + 16 * r] = x[r];
+    block_sync_lds();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = xa[S.l3 + 80 * r];
+    split_tw<REGTW, 3>(S, twf, fa, fb, fc);
+    inv_pass4(x, fa, fb, fc, Q, mu32);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xb[S.s3 + 64 * r] = x[r];
+    block_sync_lds();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = xb[S.t + 256 * r];
+    if constexpr (REGTW) inv_pass4_last(x, S.fa[4], S.fb[4], ninv, wlast, Q);
+    else inv_pass4_last(x, twf[tw_pos<2>(1)], twf[tw_pos<2>(0)], ninv, wlast, Q);
+}
+
+template <int DG, int WPS>  // WPS = waves per SIMD the register budget allows: 2 (one workgroup per CU) or 4 (two)
+__global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
+                                                                   u32 slot_stride, u32* __restrict__ acc_out) {
+    static_assert(DG == 4, "the split inverse transform is laid out for 8 waves");
+    constexpr int LOGN = 10;
+    using C = Cfg<LOGN>;
+    constexpr int N = C::N, NP = C::NP;
+    constexpr u32 R = 2 * DG, T = 64 * R, XB = 1280;
+    extern __shared__ __align__(16) u32 smem[];
+    uint2* twf = reinterpret_cast<uint2*>(smem);
+    u32* acc = reinterpret_cast<u32*>(twf + N);  // [2][NP]
+    u32* dct = acc + 2 * NP;                     // [R][NP]
+    u32* xab = dct + R * NP;                     // [2 polynomials][2 buffers][XB]
+    u32* av = xab + 4 * XB;
+
+    const u32 tid = threadIdx.x;
+    const u32 lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 Q = P.Q, q = P.q, qm = q - 1, n = P.n;
+    const bce_gate_desc g = descs[blockIdx.x % n_desc];
+    const u32 soff = (blockIdx.x / n_desc) * slot_stride;
+    bootstrap_prologue<LOGN, true, T>(P, g, soff, twf, acc, av, tid, lane, wave);
+
+    const u32 c = wave >> 2;  // this wave's inverse-transform group = accumulator component
+    constexpr bool REGTW = WPS <= 2;
+    SplitInv<REGTW> S;
+    split_inv_setup(S, twf, tid & 255u);
+    u32* const accc = acc + c * NP;
+    u32* const xa = xab + c * 2 * XB;
+    u32* const xb = xa + XB;
+
+    const uint2 ninv = make_uint2(P.Ninv, P.Ninv_s), wlast = make_uint2(P.Winv_last, P.Winv_last_s);
+    constexpr u32 rgsw = R * 2 * N;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(P.bsk), 0, (int)(n * 2 * rgsw * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t psi_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(P.psi_tab), 0, N * 4, 0x00020000);
+    // digit extraction constants (see the throughput kernel)
+    const u32 gb = P.gBits, Qh = Q >> 1;
+    u32 off = 0;
+    for (u32 l = 0; l < (u32)DG; ++l) off |= 1u << (l * gb + gb - 1);
+    const u32 offm = off - Q, bias = Q - (1u << (gb - 1));
+    // MAC item of this thread: component mc, positions mp0..mp0+3 (T == 2 * N/4: exactly one item each)
+    const u32 mc = tid / (N / 4), mp0 = (tid % (N / 4)) * 4, mpp = phys(mp0);
+    const u32 dig0 = phys(S.t);  // digit destination of register r: dig0 + 272 r  (phys(t + 256 r))
+
+    BCE_PROF_INIT();
+    for (u32 step = 0; step < n; ++step) {
+        const u32 ap = ((q - av[step]) & qm) * P.factor;
+        if (ap == 0) continue;
+        const u32 rowb = step * (2 * rgsw * 4);
+        // key rows of this step, requested now, consumed in phase 3: all 16 with the 256-register budget,
+        // the first half of each key with the 128-register one (the rest is requested in phase 3)
+        constexpr u32 PR = (WPS <= 2) ? R : R / 2;
+        uint4 kA[R], kB[R];
+#pragma unroll
+        for (u32 l = 0; l < PR; ++l) kA[l] = bsk_row(rsrc, tid * 16u, rowb + l * (2 * N * 4));
+#pragma unroll
+        for (u32 l = 0; l < PR; ++l) kB[l] = bsk_row(rsrc, tid * 16u, rowb + (rgsw + l * 2 * N) * 4);
+        // (1) inverse transforms on all 8 waves, then SignedDigitDecompose (closed form) -> dct[2l + c]
+        {
+            u32 x[4];
+            split_inverse(S, twf, accc, xa, xb, Q, P.mu32, ninv, wlast, x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const u32 u = x[r] + ((x[r] < Qh) ? off : offm);
+#pragma unroll
+                for (u32 l = 0; l < (u32)DG; ++l)
+                    dct[(2 * l + c) * NP + dig0 + 272 * r] = __builtin_amdgcn_ubfe(u, l * gb, gb) + bias;
+            }
+        }
+        BCE_PROF_MARK(0);
+        block_sync_lds();
+        BCE_PROF_MARK(1);
+        // (2) one wave per decomposed polynomial: forward NTT in place
+        ntt_forward_wave<LOGN, true, false, false>(dct + wave * NP, twf, lane, Q, P.mu32);
+        BCE_PROF_MARK(2);
+        block_sync_lds();
+        BCE_PROF_MARK(3);
+        // (3) RGSW multiply-accumulate
+        {
+            u64 sp[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (u32 l = 0; l < PR; ++l) {
+                const uint4 d = *reinterpret_cast<const uint4*>(dct + l * NP + mpp);
+                sp[0] += (u64)d.x * kA[l].x; sp[1] += (u64)d.y * kA[l].y; sp[2] += (u64)d.z * kA[l].z; sp[3] += (u64)d.w * kA[l].w;
+                sn[0] += (u64)d.x * kB[l].x; sn[1] += (u64)d.y * kB[l].y; sn[2] += (u64)d.z * kB[l].z; sn[3] += (u64)d.w * kB[l].w;
+            }
+            if constexpr (PR < R) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (u32 l = PR; l < R; ++l) kA[l] = bsk_row(rsrc, tid * 16u, rowb + l * (2 * N * 4));
+#pragma unroll
+                for (u32 l = PR; l < R; ++l) kB[l] = bsk_row(rsrc, tid * 16u, rowb + (rgsw + l * 2 * N) * 4);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (u32 l = PR; l < R; ++l) {
+                    const uint4 d = *reinterpret_cast<const uint4*>(dct + l * NP + mpp);
+                    sp[0] += (u64)d.x * kA[l].x; sp[1] += (u64)d.y * kA[l].y; sp[2] += (u64)d.z * kA[l].z; sp[3] += (u64)d.w * kA[l].w;
+                    sn[0] += (u64)d.x * kB[l].x; sn[1] += (u64)d.y * kB[l].y; sn[2] += (u64)d.z * kB[l].z; sn[3] += (u64)d.w * kB[l].w;
+                }
+            }
+            const u32 a4 = ap & 3u;
+            const uint2 Ia = make_uint2(P.I4[a4], P.I4s[a4]);
+            const uint2 Ina = make_uint2(P.I4[(4u - a4) & 3u], P.I4s[(4u - a4) & 3u]);
+            ginx_mac_tail<LOGN, true>(P, psi_rsrc, Q, ap, Ia, Ina, mp0, acc + mc * NP + mpp, sp, sn);
+        }
+        BCE_PROF_MARK(4);
+        block_sync_lds();
+        BCE_PROF_MARK(5);
+    }
+    // accumulator back to COEFFICIENT form for the extraction kernel
+    {
+        u32 x[4];
+        split_inverse(S, twf, accc, xa, xb, Q, P.mu32, ninv, wlast, x);
+        u32* out = acc_out + ((size_t)blockIdx.x * 2 + c) * N + S.t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[256 * r] = x[r];
+    }
+}
+
+size_t blind_rotate_lat_lds_bytes(const DevParams& P) {
+    const size_t N = P.N, NP = N + (N >> 6) * 4, R = 2 * P.dG;
+    return (2 * N + (2 + R) * NP + 4 * 1280 + ((P.n + 1 + 3) & ~3u)) * sizeof(u32);
 }
 
 size_t blind_rotate_lds_bytes(const DevParams& P) {
@@ -739,6 +1047,18 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n
     const int occ = P.occupancy_target;
     const bool ap = P.method_ap != 0;
     BrKernel kern = nullptr;
+    if (P.variant != 1 && P.logN == 10 && P.dG == 4 && P.lazy && !ap) {
+        // N = 1024, dG = 4 (STD128 class): the split-transform kernel, with the 256-register budget while the
+        // launch leaves every workgroup a CU of its own, else with the 128-register one (two per CU);
+        // measured against the one-wave-per-transform kernel over launch sizes 64..6144: tools/kernel_sweep.py
+        const size_t lds_lat = blind_rotate_lat_lds_bytes(P);
+        const bool alone = (P.variant == 2) || (P.variant == 0 && grid.x <= P.cu_count);
+        kern = (alone && P.variant != 3) ? k_blind_rotate_lat<4, 2> : k_blind_rotate_lat<4, 4>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lat);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, block, lds_lat, s, P, d, n_desc, slot_stride, acc_out);
+        return hipGetLastError();
+    }
     switch (P.logN) {
         case 9: kern = pick_br_dg<9>(P.dG, P.lazy != 0, occ, ap); break;
         case 10: kern = pick_br_dg<10>(P.dG, P.lazy != 0, occ, ap); break;
@@ -955,3 +1275,14 @@ hipError_t launch_pointwise_mac(const DevParams& P, u32* b, const u32* a, const 
 }
 
 }  // namespace bce
+
+#ifdef BCE_PHASE_PROF
+extern "C" int bce_debug_phase_prof(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bce::g_phase_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(bce::g_phase_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -33,6 +33,9 @@ struct DevParams {
     u32 lazy;         // 1 when the forward NTT can run without any correction (bounds in engine.cpp)
     u32 c32;          // 2^32 mod Q (folds 64-bit MAC sums of un-normalised NTT outputs)
     u32 occupancy_target;  // workgroups per CU the blind-rotation kernel is compiled for (2 or 3)
+    u32 variant;           // blind-rotation kernel choice: 0 automatic; 1 one-wave-per-transform kernel; 2 / 3 split-
+                           // transform kernel forced to its 256- / 128-register build (development knob BCE_VARIANT)
+    u32 cu_count;          // compute units of the device (automatic choice: a launch of <= cu_count workgroups)
     u32 I4[4], I4s[4];     // powers of I = psi^(N/2) (primitive 4th root of unity) and Shoup companions
     const uint2* tw_f;  // [N] (psi^brv(i), shoup), index m+i as in the CT forward NTT; the inverse
                         // transform derives psi^-k = -psi^(N-k) from the same table

@@ -19,11 +19,11 @@ import numpy as np  # noqa: E402
 
 bce = importlib.import_module("openfhe-boolean-circuit-evaluator_amd")
 lib = C.CDLL(bce.LIB_PATH)
-NAMES = ["own inverse NTT+digits", "wait barrier 1", "forward NTT", "wait barrier 2", "RGSW MAC", "wait barrier 3"]
+NAMES = ["phase 1 (thread 0: loads issue, inverse NTT, digits)", "wait barrier 1", "forward NTT", "wait barrier 2", "RGSW MAC", "wait barrier 3"]
 
 
 def main():
-    batches = [int(x) for x in sys.argv[1:]] or [1, 768, 2048]
+    batches = [int(x) for x in sys.argv[1:]] or [1, 256]
     c = bce.BinFHEContext(bce.STD128_OPT, bce.GINX)
     c.KeyGen(42)
     nmax = max(batches)
@@ -44,7 +44,7 @@ def main():
         tot = float(sum(out[:6]))
         print("batch %d: blind_rotate %.2f ms, workgroup 0 total %.0f cycles" % (nb, t["blind_rotate_ms"], tot))
         for k, name in enumerate(NAMES):
-            print("   %-24s %10d cycles  %5.1f%%" % (name, out[k], 100.0 * out[k] / tot))
+            print("   %-56s %10d cycles  %5.1f%%" % (name, out[k], 100.0 * out[k] / tot))
 
 
 main()
