@@ -413,6 +413,31 @@ __device__ __forceinline__ void ntt_forward_wave(u32* poly, const uint2* twf, u3
     wave_sync();
 }
 
+// Forward NTT (N = 1024) of a polynomial whose stages on bits 9 and 8 were already applied by the producer of
+// its coefficients: stages 7..4 on register pairs, 3..0 on plain registers -- two passes, one re-shuffle.
+// In place, natural padded layout in, bit-reversed order out, values un-normalised (see ntt_forward_wave).
+__device__ __forceinline__ void ntt_forward_wave_low8(u32* poly, const uint2* twf, u32 lane, u32 Q) {
+    constexpr int LOGN = 10;
+    {
+        u64 xp[16];
+        load_pass_pair<LOGN, 4>(poly, lane, xp);
+        fwd_stages_pair<LOGN, 4, 7, 4>(xp, lane, twf, Q);
+        store_pass_pair<LOGN, 4>(poly, lane, xp);
+    }
+    wave_sync();
+    u32 x[16];
+    load_pass<LOGN, 0>(poly, lane, x);
+    fwd_stages<LOGN, 0, 3, 0, true>(x, lane, twf, Q);
+    store_pass<LOGN, 0>(poly, lane, x);
+    wave_sync();
+}
+// one lazy Cooley-Tukey butterfly on plain registers (5 instructions; X' = X + wY, Y' = X - wY + 2Q)
+__device__ __forceinline__ void fwd_bfly(u32& X, u32& Y, uint2 w, u32 Q) {
+    const u64 t = mad64(__umulhi(Y, w.y), 0u - Q, mad64(Y, w.x, pair_of(X)));
+    Y = (X << 1) + 2 * Q - (u32)t;
+    X = (u32)t;
+}
+
 // Inverse NTT by one wave: reads `src` (bit-reversed order, values < 2Q), uses `tmp` for the
 // re-shuffles (may alias src), leaves coefficient j = (r << 6) | lane in x[r], in [0, Q).
 // ninv = N^-1, wlast = -I * N^-1 (I = psi^(N/2)), both with Shoup companions; mu32 = floor(2^32 / Q).
@@ -467,12 +492,12 @@ __device__ __forceinline__ u32 gate_const(u32 op, u32 q) {
 
 // Tail of one GINX MAC item: sp / sn are the 64-bit row sums against key+ / key- at the 4 consecutive
 // evaluation positions p0..p0+3; multiplies them by the monomials psi^(+-(2k+1)a') - 1 and accumulates
-// into the 4 accumulator words at accp.
+// into the 4 accumulator words at accp (also returned in a[], values < 2Q when LAZY).
 // I^a' and I^-a' for I = psi^(N/2): the 4 positions sit at evaluation points whose exponents differ by
 // multiples of (N/2)*a' (brv(p0+e) = brv(p0) + {0,2,1,3}*N/4).
 template <int LOGN, bool LAZY>
 __device__ __forceinline__ void ginx_mac_tail(const DevParams& P, __amdgpu_buffer_rsrc_t psi_rsrc, u32 Q, u32 ap, uint2 Ia,
-                                              uint2 Ina, u32 p0, u32* accp, const u64 (&sp)[4], const u64 (&sn)[4]) {
+                                              uint2 Ina, u32 p0, u32* accp, const u64 (&sp)[4], const u64 (&sn)[4], u32 (&a)[4]) {
     constexpr u32 N = 1u << LOGN;
     const bool odd = ap & 1u;
     const u32 k0 = __brev(p0) >> (32 - LOGN);
@@ -486,8 +511,8 @@ __device__ __forceinline__ void ginx_mac_tail(const DevParams& P, __amdgpu_buffe
     mn[1] = odd ? Q - mn[0] : mn[0];
     mp[3] = odd ? Q - mp[2] : mp[2];
     mn[3] = odd ? Q - mn[2] : mn[2];
-    uint4 a4v = *reinterpret_cast<const uint4*>(accp);
-    u32 a[4] = {a4v.x, a4v.y, a4v.z, a4v.w};
+    const uint4 a4v = *reinterpret_cast<const uint4*>(accp);
+    a[0] = a4v.x; a[1] = a4v.y; a[2] = a4v.z; a[3] = a4v.w;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         if constexpr (LAZY) {
@@ -743,7 +768,8 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
                 sn[0] += (u64)d.x * kA[l].x; sn[1] += (u64)d.y * kA[l].y; sn[2] += (u64)d.z * kA[l].z; sn[3] += (u64)d.w * kA[l].w;
             }
             }
-            ginx_mac_tail<LOGN, LAZY>(P, psi_rsrc, Q, ap, Ia, Ina, p0, acc + c * NP + pp, sp, sn);
+            u32 anew[4];
+            ginx_mac_tail<LOGN, LAZY>(P, psi_rsrc, Q, ap, Ia, Ina, p0, acc + c * NP + pp, sp, sn, anew);
         }
         BCE_PROF_MARK(4);
         __syncthreads();
@@ -771,6 +797,10 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
 //     exchanged through two ping-pong LDS buffers whose layouts are bank-conflict free on both sides
 //     with compile-time register offsets (e0: padded natural, e1: p[3:0] + 20 p[5:4] + 80 p[7:6] + 320 p[9:8],
 //     e2: p[5:0] + 80 p[7:6] + 320 p[9:8], e3: natural);
+//   * the thread <-> data mappings line up across phases, so two passes are fused away: the MAC thread owns
+//     the 4 consecutive positions of inverse pass 0 and runs it on the words it has just accumulated; after the
+//     inverse transform a thread holds coefficients t + 256 r, i.e. bits 9 and 8 in registers, and applies the
+//     first two FORWARD stages to each digit there -- the forward transform is left with 8 stages = 2 passes;
 //   * the 15 inverse twiddles of a thread do not depend on the step: they live in registers;
 //   * all 16 key rows of a step are requested at the top of the step and the barriers inside a step
 //     order LDS only, so the L2/HBM latency hides behind the transforms (64 VGPRs of loads in flight,
@@ -851,20 +881,23 @@ __device__ __forceinline__ void split_tw(const SplitInv<REGTW>& S, const uint2* 
         fc = twf[S.ic[K]];
     }
 }
-// src: evaluation-form polynomial (padded natural layout, values < 2Q); xa / xb: ping-pong exchange buffers
-// (1280 words each).  Leaves coefficient j = (r << 8) | t in x[r], in [0, Q).  Contains 4 workgroup barriers.
+// Pass 0 (stages on position bits 0, 1) of thread t's 4 consecutive evaluation-form values a[] (< 2Q): result
+// into exchange buffer xa (layout e0).  The MAC thread of the same index owns exactly these 4 positions, so
+// the kernel runs this on the freshly accumulated words instead of re-reading them.
 template <bool REGTW>
-__device__ __forceinline__ void split_inverse(const SplitInv<REGTW>& S, const uint2* twf, const u32* src, u32* xa, u32* xb, u32 Q,
-                                              u32 mu32, uint2 ninv, uint2 wlast, u32 (&x)[4]) {
+__device__ __forceinline__ void split_pass0(const SplitInv<REGTW>& S, const uint2* twf, u32 (&a)[4], u32* xa, u32 Q, u32 mu32) {
     uint2 fa, fb, fc;
-    {
-        const uint4 v = *reinterpret_cast<const uint4*>(src + S.a0);
-        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-        split_tw<REGTW, 0>(S, twf, fa, fb, fc);
-        inv_pass4(x, fa, fb, fc, Q, mu32);
-        *reinterpret_cast<uint4*>(xa + S.a0) = make_uint4(x[0], x[1], x[2], x[3]);
-    }
-    block_sync_lds();
+    split_tw<REGTW, 0>(S, twf, fa, fb, fc);
+    inv_pass4(a, fa, fb, fc, Q, mu32);
+    *reinterpret_cast<uint4*>(xa + S.a0) = make_uint4(a[0], a[1], a[2], a[3]);
+}
+// Passes 1..4: xa holds pass 0's output (a workgroup barrier after its stores is the caller's); xa / xb are the
+// ping-pong exchange buffers (1280 words each).  Leaves coefficient j = (r << 8) | t in x[r], in [0, Q).
+// Contains 3 workgroup barriers.
+template <bool REGTW>
+__device__ __forceinline__ void split_inverse_rest(const SplitInv<REGTW>& S, const uint2* twf, u32* xa, u32* xb, u32 Q, u32 mu32,
+                                                   uint2 ninv, uint2 wlast, u32 (&x)[4]) {
+    uint2 fa, fb, fc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = xa[S.l1 + 4 * r];
     split_tw<REGTW, 1>(S, twf, fa, fb, fc);
@@ -935,11 +968,19 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
     // MAC item of this thread: component mc, positions mp0..mp0+3 (T == 2 * N/4: exactly one item each)
     const u32 mc = tid / (N / 4), mp0 = (tid % (N / 4)) * 4, mpp = phys(mp0);
     const u32 dig0 = phys(S.t);  // digit destination of register r: dig0 + 272 r  (phys(t + 256 r))
+    // forward twiddles of the stages on bits 9 and 8 (wave-uniform): applied to the digits in registers
+    const uint2 w9 = twf[1], w8a = twf[2], w8b = twf[3];
+    {   // pass 0 of the first inverse transform (afterwards the MAC tail produces it)
+        const uint4 v = *reinterpret_cast<const uint4*>(accc + S.a0);
+        u32 a[4] = {v.x, v.y, v.z, v.w};
+        split_pass0(S, twf, a, xa, Q, P.mu32);
+    }
+    block_sync_lds();
 
     BCE_PROF_INIT();
     for (u32 step = 0; step < n; ++step) {
         const u32 ap = ((q - av[step]) & qm) * P.factor;
-        if (ap == 0) continue;
+        if (ap == 0) continue;  // acc unchanged: xa still holds its pass 0
         const u32 rowb = step * (2 * rgsw * 4);
         // key rows of this step, requested now, consumed in phase 3: all 16 with the 256-register budget,
         // the first half of each key with the 128-register one (the rest is requested in phase 3)
@@ -949,27 +990,35 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
         for (u32 l = 0; l < PR; ++l) kA[l] = bsk_row(rsrc, tid * 16u, rowb + l * (2 * N * 4));
 #pragma unroll
         for (u32 l = 0; l < PR; ++l) kB[l] = bsk_row(rsrc, tid * 16u, rowb + (rgsw + l * 2 * N) * 4);
-        // (1) inverse transforms on all 8 waves, then SignedDigitDecompose (closed form) -> dct[2l + c]
+        // (1) inverse transforms on all 8 waves (passes 1..4), SignedDigitDecompose in closed form, and the
+        //     first two forward stages (bits 9, 8 = this thread's 4 registers) on each digit -> dct[2l + c]
         {
-            u32 x[4];
-            split_inverse(S, twf, accc, xa, xb, Q, P.mu32, ninv, wlast, x);
+            u32 x[4], u[4];
+            split_inverse_rest(S, twf, xa, xb, Q, P.mu32, ninv, wlast, x);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const u32 u = x[r] + ((x[r] < Qh) ? off : offm);
+            for (int r = 0; r < 4; ++r) u[r] = x[r] + ((x[r] < Qh) ? off : offm);
 #pragma unroll
-                for (u32 l = 0; l < (u32)DG; ++l)
-                    dct[(2 * l + c) * NP + dig0 + 272 * r] = __builtin_amdgcn_ubfe(u, l * gb, gb) + bias;
+            for (u32 l = 0; l < (u32)DG; ++l) {
+                u32 v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_ubfe(u[r], l * gb, gb) + bias;
+                fwd_bfly(v[0], v[2], w9, Q);
+                fwd_bfly(v[1], v[3], w9, Q);
+                fwd_bfly(v[0], v[1], w8a, Q);
+                fwd_bfly(v[2], v[3], w8b, Q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dct[(2 * l + c) * NP + dig0 + 272 * r] = v[r];
             }
         }
         BCE_PROF_MARK(0);
         block_sync_lds();
         BCE_PROF_MARK(1);
-        // (2) one wave per decomposed polynomial: forward NTT in place
-        ntt_forward_wave<LOGN, true, false, false>(dct + wave * NP, twf, lane, Q, P.mu32);
+        // (2) one wave per decomposed polynomial: the remaining 8 forward stages, in place
+        ntt_forward_wave_low8(dct + wave * NP, twf, lane, Q);
         BCE_PROF_MARK(2);
         block_sync_lds();
         BCE_PROF_MARK(3);
-        // (3) RGSW multiply-accumulate
+        // (3) RGSW multiply-accumulate, then pass 0 of the next inverse transform on the new words
         {
             u64 sp[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -995,16 +1044,18 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
             const u32 a4 = ap & 3u;
             const uint2 Ia = make_uint2(P.I4[a4], P.I4s[a4]);
             const uint2 Ina = make_uint2(P.I4[(4u - a4) & 3u], P.I4s[(4u - a4) & 3u]);
-            ginx_mac_tail<LOGN, true>(P, psi_rsrc, Q, ap, Ia, Ina, mp0, acc + mc * NP + mpp, sp, sn);
+            u32 anew[4];
+            ginx_mac_tail<LOGN, true>(P, psi_rsrc, Q, ap, Ia, Ina, mp0, acc + mc * NP + mpp, sp, sn, anew);
+            split_pass0(S, twf, anew, xa, Q, P.mu32);  // mc == c, mp0 == 4 t: this thread's pass-0 registers
         }
         BCE_PROF_MARK(4);
         block_sync_lds();
         BCE_PROF_MARK(5);
     }
-    // accumulator back to COEFFICIENT form for the extraction kernel
+    // accumulator back to COEFFICIENT form for the extraction kernel (its pass 0 is already in xa)
     {
         u32 x[4];
-        split_inverse(S, twf, accc, xa, xb, Q, P.mu32, ninv, wlast, x);
+        split_inverse_rest(S, twf, xa, xb, Q, P.mu32, ninv, wlast, x);
         u32* out = acc_out + ((size_t)blockIdx.x * 2 + c) * N + S.t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[256 * r] = x[r];
