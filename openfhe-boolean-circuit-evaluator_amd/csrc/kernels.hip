@@ -225,14 +225,14 @@ __device__ __forceinline__ void fwd_stage_pair(u64 (&x)[Cfg<LOGN>::E], u32 lane,
         x[r] = t;
     }
 }
-// First stage (bit LOGN-1, one twiddle) straight from PLAIN registers into pairs: only the X operands are
+// First stage of a pass whose top register bit is the stage bit (one twiddle per lane: registers r and r + E/2),
+// straight from PLAIN registers into pairs: only the X operands are
 // needed as 64-bit addends, the Y' results are born in pair low halves -- no register-pair set-up moves
 // for the 16-byte loads of the lane-major hand-off.
 template <int LOGN>
-__device__ __forceinline__ void fwd_first_stage_pair(const u32 (&x)[Cfg<LOGN>::E], u64 (&xp)[Cfg<LOGN>::E], const uint2* tw, u32 Q) {
+__device__ __forceinline__ void fwd_first_stage_pair(const u32 (&x)[Cfg<LOGN>::E], u64 (&xp)[Cfg<LOGN>::E], uint2 w, u32 Q) {
     constexpr int E = Cfg<LOGN>::E, Hh = E / 2;
     const u32 Q2 = 2 * Q, negQ = 0u - Q;
-    const uint2 w = tw[1];
 #pragma unroll
     for (int r = 0; r < Hh; ++r) {
         const u32 X = x[r], Y = x[r + Hh];
@@ -368,7 +368,7 @@ __device__ __forceinline__ void ntt_forward_wave(u32* poly, const uint2* twf, u3
         u64 xp[C::E];
         if constexpr (LM_IN) {
             load_lm<LOGN>(poly, lane, x);
-            fwd_first_stage_pair<LOGN>(x, xp, twf, Q);
+            fwd_first_stage_pair<LOGN>(x, xp, twf[1], Q);
             fwd_stages_pair<LOGN, 6, LOGN - 2, 6>(xp, lane, twf, Q);
         } else {
             load_pass_pair<LOGN, 6>(poly, lane, xp);
@@ -414,7 +414,7 @@ __device__ __forceinline__ void ntt_forward_wave(u32* poly, const uint2* twf, u3
 }
 
 // Forward NTT (N = 1024) of a polynomial whose stages on bits 9 and 8 were already applied by the producer of
-// its coefficients: stages 7..4 on register pairs, 3..0 on plain registers -- two passes, one re-shuffle.
+// its coefficients: two passes of four stages on register pairs, one re-shuffle.
 // In place, natural padded layout in, bit-reversed order out, values un-normalised (see ntt_forward_wave).
 __device__ __forceinline__ void ntt_forward_wave_low8(u32* poly, const uint2* twf, u32 lane, u32 Q) {
     constexpr int LOGN = 10;
@@ -426,8 +426,12 @@ __device__ __forceinline__ void ntt_forward_wave_low8(u32* poly, const uint2* tw
     }
     wave_sync();
     u32 x[16];
+    u64 xp[16];
     load_pass<LOGN, 0>(poly, lane, x);
-    fwd_stages<LOGN, 0, 3, 0, true>(x, lane, twf, Q);
+    fwd_first_stage_pair<LOGN>(x, xp, twf[tw_pos<64>(lane)], Q);  // stage 3: block m = 64, index j >> 4 = lane
+    fwd_stages_pair<LOGN, 0, 2, 0>(xp, lane, twf, Q);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = (u32)xp[r];
     store_pass<LOGN, 0>(poly, lane, x);
     wave_sync();
 }
@@ -894,10 +898,13 @@ __device__ __forceinline__ void split_pass0(const SplitInv<REGTW>& S, const uint
 // Passes 1..4: xa holds pass 0's output (a workgroup barrier after its stores is the caller's); xa / xb are the
 // ping-pong exchange buffers (1280 words each).  Leaves coefficient j = (r << 8) | t in x[r], in [0, Q).
 // Contains 3 workgroup barriers.
-template <bool REGTW>
+// at_pass(integral_constant<int, k>) is called at the start of pass k = 1..4 (the kernel spreads its key-row
+// requests over the passes with it: 16 back-to-back 1-KiB loads per wave would block on the memory queue).
+template <bool REGTW, typename F>
 __device__ __forceinline__ void split_inverse_rest(const SplitInv<REGTW>& S, const uint2* twf, u32* xa, u32* xb, u32 Q, u32 mu32,
-                                                   uint2 ninv, uint2 wlast, u32 (&x)[4]) {
+                                                   uint2 ninv, uint2 wlast, u32 (&x)[4], F&& at_pass) {
     uint2 fa, fb, fc;
+    at_pass(std::integral_constant<int, 1>{});
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = xa[S.l1 + 4 * r];
     split_tw<REGTW, 1>(S, twf, fa, fb, fc);
@@ -905,6 +912,7 @@ __device__ __forceinline__ void split_inverse_rest(const SplitInv<REGTW>& S, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) xb[S.s1 + 4 * r] = x[r];
     block_sync_lds();
+    at_pass(std::integral_constant<int, 2>{});
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = xb[S.l2 + 20 * r];
     split_tw<REGTW, 2>(S, twf, fa, fb, fc);
@@ -912,6 +920,7 @@ __device__ __forceinline__ void split_inverse_rest(const SplitInv<REGTW>& S, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) xa[S.s2 + 16 * r] = x[r];
     block_sync_lds();
+    at_pass(std::integral_constant<int, 3>{});
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = xa[S.l3 + 80 * r];
     split_tw<REGTW, 3>(S, twf, fa, fb, fc);
@@ -919,6 +928,7 @@ __device__ __forceinline__ void split_inverse_rest(const SplitInv<REGTW>& S, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) xb[S.s3 + 64 * r] = x[r];
     block_sync_lds();
+    at_pass(std::integral_constant<int, 4>{});
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = xb[S.t + 256 * r];
     if constexpr (REGTW) inv_pass4_last(x, S.fa[4], S.fb[4], ninv, wlast, Q);
@@ -982,19 +992,24 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
         const u32 ap = ((q - av[step]) & qm) * P.factor;
         if (ap == 0) continue;  // acc unchanged: xa still holds its pass 0
         const u32 rowb = step * (2 * rgsw * 4);
-        // key rows of this step, requested now, consumed in phase 3: all 16 with the 256-register budget,
-        // the first half of each key with the 128-register one (the rest is requested in phase 3)
+        // key rows of this step, requested during phase 1 (a quarter at the start of each inverse pass),
+        // consumed in phase 3: all 16 with the 256-register budget, the first half of each key with the
+        // 128-register one (the rest is requested in phase 3)
         constexpr u32 PR = (WPS <= 2) ? R : R / 2;
         uint4 kA[R], kB[R];
+        auto request_rows = [&](auto kc) {
+            constexpr u32 k = decltype(kc)::value - 1, G = PR / 4;  // pass k+1 requests rows [k*G, (k+1)*G) of each key
 #pragma unroll
-        for (u32 l = 0; l < PR; ++l) kA[l] = bsk_row(rsrc, tid * 16u, rowb + l * (2 * N * 4));
-#pragma unroll
-        for (u32 l = 0; l < PR; ++l) kB[l] = bsk_row(rsrc, tid * 16u, rowb + (rgsw + l * 2 * N) * 4);
+            for (u32 l = k * G; l < (k + 1) * G; ++l) {
+                kA[l] = bsk_row(rsrc, tid * 16u, rowb + l * (2 * N * 4));
+                kB[l] = bsk_row(rsrc, tid * 16u, rowb + (rgsw + l * 2 * N) * 4);
+            }
+        };
         // (1) inverse transforms on all 8 waves (passes 1..4), SignedDigitDecompose in closed form, and the
         //     first two forward stages (bits 9, 8 = this thread's 4 registers) on each digit -> dct[2l + c]
         {
             u32 x[4], u[4];
-            split_inverse_rest(S, twf, xa, xb, Q, P.mu32, ninv, wlast, x);
+            split_inverse_rest(S, twf, xa, xb, Q, P.mu32, ninv, wlast, x, request_rows);
 #pragma unroll
             for (int r = 0; r < 4; ++r) u[r] = x[r] + ((x[r] < Qh) ? off : offm);
 #pragma unroll
@@ -1055,7 +1070,7 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
     // accumulator back to COEFFICIENT form for the extraction kernel (its pass 0 is already in xa)
     {
         u32 x[4];
-        split_inverse_rest(S, twf, xa, xb, Q, P.mu32, ninv, wlast, x);
+        split_inverse_rest(S, twf, xa, xb, Q, P.mu32, ninv, wlast, x, [](auto) {});
         u32* out = acc_out + ((size_t)blockIdx.x * 2 + c) * N + S.t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[256 * r] = x[r];

@@ -112,6 +112,32 @@ def test_std128_gates_bit_exact(std128, bce):
         assert o.decrypt(out[i]) == _truth(g, a, b)
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_std128_every_blind_rotation_kernel_bit_exact(std128, bce, variant, monkeypatch):
+    """N = 1024 / dG = 4 has three blind-rotation kernels (one wave per inverse transform; split transform at
+    one / two workgroups per CU) chosen by launch size; BCE_VARIANT pins one at context creation.  Each must
+    reproduce the oracle's accumulator and final ciphertext bit for bit."""
+    o, c_auto = std128
+    monkeypatch.setenv("BCE_VARIANT", str(variant))
+    c = bce.BinFHEContext(bce.STD128_OPT, bce.GINX)
+    c.import_keys(o.sk(), o.z(), o.bsk(), o.ksk())
+    cases = [x for x in _gate_cases(o, base=3000 + 100 * variant) if x[0] in (bce.AND, bce.NOR, bce.XOR_FAST)][1:5]
+    nb = len(cases)
+    for ctx in (c, c_auto):
+        ctx.pool_reserve(3 * nb)
+        ctx.lwe_write(np.arange(2 * nb, dtype=np.uint32), np.concatenate([np.stack([ca, cb]) for (_, _, _, ca, cb) in cases]))
+    descs = [(g, 2 * i, 2 * i + 1, 2 * nb + i) for i, (g, _, _, _, _) in enumerate(cases)]
+    acc, lweN, ks = c.debug_eval_stages(descs)
+    out = c.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32))
+    c_auto.EvalGates(bce.make_descs(descs))
+    assert np.array_equal(out, c_auto.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32)))
+    for i, (g, a, b, ca, cb) in enumerate(cases):
+        r_acc = o.blind_rotate(g, o.gate_prep(g, ca, cb))
+        assert np.array_equal(acc[i], r_acc), "accumulator differs, variant %d case %d" % (variant, i)
+        assert np.array_equal(out[i], o.eval_bingate(g, ca, cb))
+        assert o.decrypt(out[i]) == _truth(g, a, b)
+
+
 def test_folded_not_refresh_and_unary(toy, bce):
     """neg0/neg1 folding == explicit EvalNOT; REFRESH == Bootstrap(); NOT/COPY ops."""
     o, c = toy
