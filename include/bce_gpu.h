@@ -63,12 +63,25 @@ typedef struct bce_gate_desc {
     uint32_t neg1;
 } bce_gate_desc;
 
+/* which blind-rotation kernel a launch used (chosen by parameter set and launch size) */
+enum bce_br_kernel {
+    BCE_BR_WAVE_PER_TRANSFORM = 0, /* k_blind_rotate: one wave per (inverse) transform, up to 3 workgroups / CU */
+    BCE_BR_SPLIT_X1 = 1,           /* k_blind_rotate_lat<4,2>: split inverse transform, launches of <= #CU workgroups */
+    BCE_BR_SPLIT_X2 = 2,           /* k_blind_rotate_lat<4,4>: same, register budget for two workgroups per CU */
+    BCE_BR_WORD64 = 3,             /* k_blind_rotate64: ring modulus >= 2^28 */
+    BCE_BR_KERNELS = 4
+};
+
 /* cumulative device timing, measured with HIP events on the engine's stream */
 typedef struct bce_timing {
-    double   blind_rotate_ms;   /* sum over launches of the blind-rotation kernel */
+    double   blind_rotate_ms;   /* sum over launches of the blind-rotation kernels */
     double   tail_ms;           /* extract + modswitch + keyswitch + modswitch    */
     uint64_t blind_rotate_launches;
     uint64_t bootstraps;        /* gate-bootstraps executed (NOT/COPY not counted) */
+    /* the same three blind-rotation figures per kernel (index: enum bce_br_kernel) */
+    double   br_ms[BCE_BR_KERNELS];
+    uint64_t br_launches[BCE_BR_KERNELS];
+    uint64_t br_bootstraps[BCE_BR_KERNELS];
 } bce_timing;
 
 /* ---- context ----------------------------------------------------------- */

@@ -41,9 +41,14 @@ class GateDesc(C.Structure):
                 ("out", C.c_uint32), ("neg0", C.c_uint32), ("neg1", C.c_uint32)]
 
 
+BR_KERNEL_NAMES = ["k_blind_rotate (one wave per transform)", "k_blind_rotate_lat<4,2> (split transform, 1 workgroup/CU)",
+                   "k_blind_rotate_lat<4,4> (split transform, 2 workgroups/CU)", "k_blind_rotate64 (64-bit modulus)"]
+
+
 class Timing(C.Structure):
     _fields_ = [("blind_rotate_ms", C.c_double), ("tail_ms", C.c_double),
-                ("blind_rotate_launches", C.c_uint64), ("bootstraps", C.c_uint64)]
+                ("blind_rotate_launches", C.c_uint64), ("bootstraps", C.c_uint64),
+                ("br_ms", C.c_double * 4), ("br_launches", C.c_uint64 * 4), ("br_bootstraps", C.c_uint64 * 4)]
 
 
 ENGINE_SYMBOLS = [
@@ -242,7 +247,9 @@ class BinFHEContext:
         t = Timing()
         self._ck(self._L.bce_timing_get(self.h, C.byref(t)))
         return {"blind_rotate_ms": t.blind_rotate_ms, "tail_ms": t.tail_ms,
-                "blind_rotate_launches": int(t.blind_rotate_launches), "bootstraps": int(t.bootstraps)}
+                "blind_rotate_launches": int(t.blind_rotate_launches), "bootstraps": int(t.bootstraps),
+                "by_kernel": [{"kernel": BR_KERNEL_NAMES[k], "ms": t.br_ms[k], "launches": int(t.br_launches[k]),
+                               "bootstraps": int(t.br_bootstraps[k])} for k in range(4)]}
 
     def bytes_per_bootstrap(self):
         return int(self._L.bce_bytes_per_bootstrap(self.h))

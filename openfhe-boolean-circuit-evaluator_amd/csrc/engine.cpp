@@ -348,7 +348,8 @@ void drain_timing(bce_ctx* c) {
     for (auto& p : c->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            if (p.kind == 0) c->timing.blind_rotate_ms += ms; else c->timing.tail_ms += ms;
+            if (p.kind < BCE_BR_KERNELS) { c->timing.blind_rotate_ms += ms; c->timing.br_ms[p.kind] += ms; }
+            else c->timing.tail_ms += ms;
         }
         c->free_events.push_back(p);
     }
@@ -480,15 +481,19 @@ int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances,
         rc = stage_descs(c, boot.data(), boot.size(), &dd, &slot);
         if (rc) return rc;
         EventPair e0 = get_events(c, 0);
+        int kid = BCE_BR_WORD64;
         hipEventRecord(e0.a, c->stream);
         if (c->is64) HIP_TRY(c, launch_blind_rotate64(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u64*>(c->d_acc), c->stream));
-        else HIP_TRY(c, launch_blind_rotate(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u32*>(c->d_acc), c->stream));
+        else HIP_TRY(c, launch_blind_rotate(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u32*>(c->d_acc), c->stream, &kid));
         hipEventRecord(e0.b, c->stream);
+        e0.kind = kid;
         c->pending.push_back(e0);
+        c->timing.br_launches[kid] += 1;
+        c->timing.br_bootstraps[kid] += nb;
         u32 *d_lweN = nullptr, *d_ks = nullptr;
         if (dbg_lweN) HIP_TRY(c, hipMalloc(&d_lweN, nb * (c->N + 1) * sizeof(u32)));
         if (dbg_ks) HIP_TRY(c, hipMalloc(&d_ks, nb * (c->n + 1) * sizeof(u32)));
-        EventPair e1 = get_events(c, 1);
+        EventPair e1 = get_events(c, BCE_BR_KERNELS);  // kind >= BCE_BR_KERNELS: tail
         hipEventRecord(e1.a, c->stream);
         HIP_TRY(c, launch_tail(c->P, dd, (u32)boot.size(), instances, slot_stride, c->d_acc, d_lweN, d_ks, c->stream));
         hipEventRecord(e1.b, c->stream);

@@ -994,7 +994,7 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
         const u32 rowb = step * (2 * rgsw * 4);
         // key rows of this step, requested during phase 1 (a quarter at the start of each inverse pass),
         // consumed in phase 3: all 16 with the 256-register budget, the first half of each key with the
-        // 128-register one (the rest is requested in phase 3)
+        // 128-register one (the rest is requested at the end of phase 2)
         constexpr u32 PR = (WPS <= 2) ? R : R / 2;
         uint4 kA[R], kB[R];
         auto request_rows = [&](auto kc) {
@@ -1031,30 +1031,24 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
         // (2) one wave per decomposed polynomial: the remaining 8 forward stages, in place
         ntt_forward_wave_low8(dct + wave * NP, twf, lane, Q);
         BCE_PROF_MARK(2);
+        if constexpr (PR < R) {
+            // 128-register build: the transform's registers are free again -- request the second half of the
+            // key rows before waiting for the other waves (the barrier orders LDS only)
+#pragma unroll
+            for (u32 l = PR; l < R; ++l) kA[l] = bsk_row(rsrc, tid * 16u, rowb + l * (2 * N * 4));
+#pragma unroll
+            for (u32 l = PR; l < R; ++l) kB[l] = bsk_row(rsrc, tid * 16u, rowb + (rgsw + l * 2 * N) * 4);
+        }
         block_sync_lds();
         BCE_PROF_MARK(3);
         // (3) RGSW multiply-accumulate, then pass 0 of the next inverse transform on the new words
         {
             u64 sp[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (u32 l = 0; l < PR; ++l) {
+            for (u32 l = 0; l < R; ++l) {
                 const uint4 d = *reinterpret_cast<const uint4*>(dct + l * NP + mpp);
                 sp[0] += (u64)d.x * kA[l].x; sp[1] += (u64)d.y * kA[l].y; sp[2] += (u64)d.z * kA[l].z; sp[3] += (u64)d.w * kA[l].w;
                 sn[0] += (u64)d.x * kB[l].x; sn[1] += (u64)d.y * kB[l].y; sn[2] += (u64)d.z * kB[l].z; sn[3] += (u64)d.w * kB[l].w;
-            }
-            if constexpr (PR < R) {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (u32 l = PR; l < R; ++l) kA[l] = bsk_row(rsrc, tid * 16u, rowb + l * (2 * N * 4));
-#pragma unroll
-                for (u32 l = PR; l < R; ++l) kB[l] = bsk_row(rsrc, tid * 16u, rowb + (rgsw + l * 2 * N) * 4);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (u32 l = PR; l < R; ++l) {
-                    const uint4 d = *reinterpret_cast<const uint4*>(dct + l * NP + mpp);
-                    sp[0] += (u64)d.x * kA[l].x; sp[1] += (u64)d.y * kA[l].y; sp[2] += (u64)d.z * kA[l].z; sp[3] += (u64)d.w * kA[l].w;
-                    sn[0] += (u64)d.x * kB[l].x; sn[1] += (u64)d.y * kB[l].y; sn[2] += (u64)d.z * kB[l].z; sn[3] += (u64)d.w * kB[l].w;
-                }
             }
             const u32 a4 = ap & 3u;
             const uint2 Ia = make_uint2(P.I4[a4], P.I4s[a4]);
@@ -1106,7 +1100,8 @@ BrKernel pick_br_dg(u32 dG, bool lazy, int occ, bool ap) {
 }  // namespace
 
 hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
-                               u32* acc_out, hipStream_t s) {
+                               u32* acc_out, hipStream_t s, int* kernel_id) {
+    if (kernel_id) *kernel_id = BCE_BR_WAVE_PER_TRANSFORM;
     const u32 R = 2 * P.dG;
     const dim3 grid(n_desc * instances), block(64 * R);
     const size_t lds = blind_rotate_lds_bytes(P);
@@ -1119,7 +1114,9 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n
         // measured against the one-wave-per-transform kernel over launch sizes 64..6144: tools/kernel_sweep.py
         const size_t lds_lat = blind_rotate_lat_lds_bytes(P);
         const bool alone = (P.variant == 2) || (P.variant == 0 && grid.x <= P.cu_count);
-        kern = (alone && P.variant != 3) ? k_blind_rotate_lat<4, 2> : k_blind_rotate_lat<4, 4>;
+        const bool x1 = alone && P.variant != 3;
+        kern = x1 ? k_blind_rotate_lat<4, 2> : k_blind_rotate_lat<4, 4>;
+        if (kernel_id) *kernel_id = x1 ? BCE_BR_SPLIT_X1 : BCE_BR_SPLIT_X2;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lat);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, block, lds_lat, s, P, d, n_desc, slot_stride, acc_out);

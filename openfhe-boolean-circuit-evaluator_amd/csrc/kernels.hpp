@@ -58,8 +58,9 @@ struct DevParams {
 size_t blind_rotate_lds_bytes(const DevParams& P);
 
 // acc_out: u32 [n_boot][2][N], COEFFICIENT domain, values in [0, Q)
+// *kernel_id (optional) receives the enum bce_br_kernel value of the kernel that was launched
 hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances,
-                               u32 slot_stride, u32* acc_out, hipStream_t s);
+                               u32 slot_stride, u32* acc_out, hipStream_t s, int* kernel_id = nullptr);
 
 // extract + ModSwitch(Q->qKS) + KeySwitch + ModSwitch(qKS->q) -> pool[out]
 // dbg_lweN: u32 [n_boot][N+1] or null; dbg_ks: u32 [n_boot][n+1] or null
