@@ -195,7 +195,7 @@ def main():
 
     traffic = None
     try:  # HBM/fabric bytes per launch from the committed --pmc passes of this same default command
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")))
         if (args.instances == tj.get("instances_per_gpu") and args.circuit == "AES-expanded.txt" and args.paramset == "STD128_OPT"
                 and shard_mode == 0 and args.relevel == tj.get("relevel") and not args.xor_fast):
             traffic = tj  # used below only if it was measured on the kernel that dominates this run
@@ -238,7 +238,7 @@ def main():
                 "bound": "hbm", "kernel": dom["kernel"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic["hbm_bytes_per_launch"] if traffic and traffic.get("bench_kernel") == dom["kernel"] else None,
-                "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json)",
+                "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01b_pmc_traffic.json)",
                 "algorithmic_bytes_per_launch": bpb * dom["bootstraps"] / max(1, dom["launches"]),
                 "bytes_per_bootstrap": bpb,
                 # when the key is reused from cache across a batch, also state the compulsory

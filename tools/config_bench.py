@@ -19,6 +19,7 @@ CONFIGS = [
     ("1 adder_2bit TOY GINX", "adder_2bit.out", "out", "TOY", "GINX", [1]),
     ("2 adder_64bit STD128_OPT GINX", "adder_64bit.txt", "old", "STD128_OPT", "GINX", [1, 64, 256]),
     ("3 AES-expanded STD128_OPT GINX", "AES-expanded.txt", "old", "STD128_OPT", "GINX", [1, 16]),
+    ("3r AES-expanded STD128_OPT GINX bootstrap-depth schedule", "AES-expanded.txt", "old", "STD128_OPT", "GINX", [1, 32]),
     ("4 sha256 (new format) STD128_OPT GINX", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
     ("5 adder_64bit STD192 AP", "adder_64bit.txt", "old", "STD192", "AP", [64]),
     ("5b AES-expanded STD192 AP", "AES-expanded.txt", "old", "STD192", "AP", [2]),
@@ -55,6 +56,8 @@ def main():
             c.Clock()
             want = [c.Outputs(k)[0] for k in range(K)]
             c.Reset(); c.setEncrypted(True)
+            if "bootstrap-depth" in name:
+                c.setRelevel(True)
             for k in range(K):
                 c.SetInput(ins[k], instance=k)
             c.Clock()                      # warm-up

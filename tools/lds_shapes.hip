@@ -4,6 +4,10 @@
 #include <cstdio>
 #include <cstdint>
 
+typedef uint32_t u32;
+__device__ __forceinline__ u32 phys_(u32 j) { return j + ((j >> 6) << 2); }
+__device__ __forceinline__ u32 xlay1_(u32 p) { return (p & 15u) + 20u * ((p >> 4) & 3u) + 80u * ((p >> 6) & 3u) + 320u * (p >> 8); }
+__device__ __forceinline__ u32 xlay2_(u32 p) { return (p & 63u) + 80u * ((p >> 6) & 3u) + 320u * (p >> 8); }
 __device__ __forceinline__ uint32_t swz(uint32_t L) { return ((L >> 1) & 3u) ^ (((L >> 3) & 1u) * 3u); }
 
 // shape -> byte address for lane `l`, sub-instruction g (0..3)
@@ -19,6 +23,26 @@ __device__ __forceinline__ uint32_t addr_of(int shape, uint32_t l, uint32_t g) {
         case 7: return 4u * (64u * g + 16u * (l & 3u) + 4u * (((l >> 2) & 7u) >> 1) + 2u * ((l >> 2) & 1u) + (l >> 5));  // b32 scatter into lane-major B
         case 8: return 4u * (68u * (l >> 2) + 4u * g + (((l & 1u) << 1) + ((l & 3u) >> 1)));  // b32 scatter into C
         case 9: return 4u * (16u * l + 4u * (l >> 2) + g);                 // b32 strided 16 words (transposed read)
+        // ---- the split inverse transform's exchange layouts (kernels.hip), thread t = lane, register r = g ----
+        case 10: { u32 pb = ((l >> 2) << 4) | (l & 3u); return 4u * (phys_(pb) + 4u * g); }            // e0 load
+        case 11: { u32 pb = ((l >> 2) << 4) | (l & 3u); return 4u * (xlay1_(pb) + 4u * g); }           // e1 store
+        case 12: { u32 pb = ((l >> 4) << 6) | (l & 15u); return 4u * (xlay1_(pb) + 20u * g); }         // e1 load
+        case 13: { u32 pb = ((l >> 4) << 6) | (l & 15u); return 4u * (xlay2_(pb) + 16u * g); }         // e2 store
+        case 14: return 4u * (xlay2_(l & 63u) + 80u * g);                                                // e2 load
+        case 15: return 4u * ((l & 63u) + 64u * g);                                                      // e3 store
+        case 16: return 4u * (l + 256u * g);                                                             // e3 load
+        case 17: return 4u * (phys_(l) + 272u * g);                                                      // digit store
+        case 18: { u32 j = ((l >> 4) << 8) | (g << 4) | (l & 15u); return 4u * phys_(j); }              // forward pass A load/store (r = g)
+        case 19: { u32 j = ((l >> 4) << 8) | ((g + 4u) << 4) | (l & 15u); return 4u * phys_(j); }       // same, r = g + 4
+        case 20: return 4u * phys_(4u * l) + 16u * 0u + 4352u * g;                                       // MAC b128 reads of dct rows (consecutive 16 B, padded)
+        // candidates
+        case 30: { u32 pb = ((l >> 2) << 4) | (l & 3u); return 4u * (pb + 4u * (pb >> 4) + 4u * g); }   // e0' load: pad 4 words per 16
+        case 31: return 4u * (4u * l + 4u * (l >> 2)) + 5120u * g;                                       // e0' b128 store (thread t -> 4t)
+        case 32: return 16u * l + 16u * (l >> 3) + 8192u * g;    // consecutive 16 B, 16-B pad every 8 lanes
+        case 33: return 16u * l + 16u * (l >> 5) + 8192u * g;    // ... every 32 lanes
+        case 34: return 16u * l + 32u * (l >> 4) + 8192u * g;    // 32-B pad every 16 lanes
+        case 35: return 16u * l + 64u * (l >> 4) + 8192u * g;    // 64-B pad every 16 lanes
+        case 36: return 16u * l + 128u * (l >> 4) + 8192u * g;   // 128-B pad every 16 lanes
         default: return 4u * l;
     }
 }
@@ -71,6 +95,14 @@ void run(const char* name, int shape, uint32_t* d) {
 
 int main() {
     uint32_t* d; hipMalloc(&d, 256 * 1024 * 4);
+    run<0>("ds_read_b32", 30, d);
+    run<5>("ds_write_b128", 31, d);
+    run<2>("ds_read_b128", 31, d);
+    for (int s : {32, 33, 34, 35, 36}) run<2>("ds_read_b128", s, d);
+    for (int s : {10, 12, 14, 16, 18, 19}) run<0>("ds_read_b32", s, d);
+    for (int s : {11, 13, 15, 17, 18, 19}) run<3>("ds_write_b32", s, d);
+    run<2>("ds_read_b128", 20, d);
+    run<5>("ds_write_b128", 20, d);
     for (int s : {0, 1, 2, 3}) run<2>("ds_read_b128", s, d);
     for (int s : {0, 1, 2, 3}) run<5>("ds_write_b128", s, d);
     for (int s : {4, 5, 6, 7, 8, 9}) run<0>("ds_read_b32", s, d);
