@@ -26,22 +26,10 @@
 
 namespace bce {
 
-// Development aid (never defined in the shipped build): -DBCE_PHASE_PROF accumulates, for workgroup 0,
-// the cycles between the barriers of a blind-rotation step; read back with bce_debug_phase_prof().
+#include "phase_prof.hpp"
 #ifdef BCE_PHASE_PROF
 __device__ unsigned long long g_phase_prof[8];
-#define BCE_PROF_INIT() unsigned long long prof_t_ = __builtin_readcyclecounter()
-#define BCE_PROF_MARK(slot)                                                         \
-    do {                                                                            \
-        if (blockIdx.x == 0 && threadIdx.x == 0) {                                  \
-            const unsigned long long now_ = __builtin_readcyclecounter();           \
-            g_phase_prof[slot] += now_ - prof_t_;                                   \
-            prof_t_ = now_;                                                         \
-        }                                                                           \
-    } while (0)
-#else
-#define BCE_PROF_INIT() do {} while (0)
-#define BCE_PROF_MARK(slot) do {} while (0)
+#define BCE_PROF_ARRAY ::bce::g_phase_prof
 #endif
 
 // ---------------------------------------------------------------------------------------

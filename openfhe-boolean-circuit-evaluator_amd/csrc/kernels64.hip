@@ -10,9 +10,16 @@
 // (2 + 2*dG) padded polynomials of N = 2048 u64 words already take 139 KiB of the 160 KiB LDS.
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 #include "kernels.hpp"
+#include "phase_prof.hpp"
 
 namespace bce {
+#ifdef BCE_PHASE_PROF
+__device__ unsigned long long g_phase_prof64[8];
+#define BCE_PROF_ARRAY ::bce::g_phase_prof64
+#endif
 namespace w64 {
 
 __device__ __forceinline__ u64 csub(u64 x, u64 m) { return min(x, x - m); }
@@ -55,6 +62,22 @@ struct Cfg {
     static constexpr int F2LO = (6 > LE) ? 6 - LE : 0;
     static_assert(LOGN >= 9 && LOGN <= 11, "supported ring sizes: 512, 1024, 2048");
 };
+
+// Workgroup barrier that orders LDS traffic only (__syncthreads() would also drain the key-row loads in flight)
+__device__ __forceinline__ void block_sync_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// 16 bytes of a key row through a buffer resource: wave-uniform base + SGPR row offset + one per-thread offset
+__device__ __forceinline__ ulonglong2 key_row(__amdgpu_buffer_rsrc_t rsrc, u32 voff, u32 soff) {
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return make_ulonglong2(((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
+}
+
+template <typename F, u32... K>
+__device__ __forceinline__ void for_each_index(F&& f, std::integer_sequence<u32, K...>) {
+    (f(std::integral_constant<u32, K>{}), ...);
+}
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -194,7 +217,9 @@ __device__ __forceinline__ u32 gate_const(u32 op, u32 q) {
     }
 }
 
-template <int LOGN, int DG, bool AP>
+// NBUF_ / NPRE_: depth of the key-row software pipeline (items in flight / requested before the transforms);
+// the defaults are the deepest that compile without scratch at N = 2048 (GINX items carry two keys' rows)
+template <int LOGN, int DG, bool AP, u32 NBUF_ = (AP ? 3 : 2), u32 NPRE_ = (AP ? 2 : 1)>
 __global__ __launch_bounds__(128 * DG) void k_blind_rotate64(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
                                                               u32 slot_stride, u64* __restrict__ acc_out) {
     using C = Cfg<LOGN>;
@@ -253,6 +278,7 @@ __global__ __launch_bounds__(128 * DG) void k_blind_rotate64(DevParams P, const 
     constexpr size_t rgsw = (size_t)R * 2 * N;
     const u64* __restrict__ bsk = P.bsk64;
     const u32 nsteps = AP ? n * P.dR : n;
+    BCE_PROF_INIT();
     for (u32 step = 0; step < nsteps; ++step) {
         u32 ap = 0;
         const u64* bk;
@@ -268,15 +294,48 @@ __global__ __launch_bounds__(128 * DG) void k_blind_rotate64(DevParams P, const 
             if (a0 == 0) continue;
             bk = bsk + (((size_t)i * P.baseR + a0) * P.dR + k) * rgsw;
         }
+        // ---- key rows: software pipeline.  A thread owns the MAC items tid, tid + T, ... (2 positions each);
+        // the rows of one item are ROWS 16-byte loads.  The first NPRE items are requested here, before the
+        // transforms (the barriers below order LDS only), up to NBUF at the start of the MAC phase, item k + NBUF
+        // when item k is done.
+        constexpr u32 ITEMS = (2u * (N / 2) + T - 1) / T;       // per thread, last one guarded
+        constexpr u32 ROWS = AP ? R : 2 * R;
+        constexpr u32 NBUF = NBUF_;   // items in flight
+        constexpr u32 NPRE = NPRE_;   // of which requested before the transforms
+        // one resource per step: base = this step's RGSW key(s), bounds = their size
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<u64*>(bk), 0, (int)((AP ? 1 : 2) * rgsw * sizeof(u64)), 0x00020000);
+        ulonglong2 kb[NBUF][ROWS];
+        // the per-item address arithmetic must stay INSIDE the step loop: hoisted, its ~30 loop-invariant values
+        // would live across the transforms, which already use the whole register file (scratch reloads per step)
+        u32 tid_v = tid, lane_v = lane;
+        asm volatile("" : "+v"(tid_v), "+v"(lane_v));
+        auto request = [&](auto kc) {
+            constexpr u32 k = decltype(kc)::value;
+            if constexpr (k < ITEMS) {
+                const u32 item = tid_v + k * T;
+                if (k + 1 < ITEMS || item < 2u * (N / 2)) {
+                    const u32 c = item / (N / 2), p0 = (item % (N / 2)) * 2;
+                    const u32 voff = (c * N + p0) * 8u;
+#pragma unroll
+                    for (u32 l = 0; l < R; ++l) {
+                        kb[k % NBUF][l] = key_row(rsrc, voff, l * (2 * N * 8));
+                        if constexpr (!AP) kb[k % NBUF][R + l] = key_row(rsrc, voff, (u32)(rgsw * 8) + l * (2 * N * 8));
+                    }
+                }
+            }
+        };
+        if constexpr (NPRE >= 1) request(std::integral_constant<u32, 0>{});
+        if constexpr (NPRE >= 2) request(std::integral_constant<u32, 1>{});
         if (wave < 2) {
             u64 x[E];
-            ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, tw, lane, Q, ninv, x);
+            ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, tw, lane_v, Q, ninv, x);
             const int gsh = 64 - (int)P.gBits;
             const u64 Qh = Q >> 1;
 #pragma unroll
             for (int r = 0; r < E; ++r) {
                 long long d = (x[r] < Qh) ? (long long)x[r] : (long long)x[r] - (long long)Q;
-                const u32 pj = phys(((u32)r << 6) | lane);
+                const u32 pj = phys(((u32)r << 6) | lane_v);
 #pragma unroll
                 for (u32 l = 0; l < (u32)DG; ++l) {
                     long long rem = (long long)((u64)d << gsh) >> gsh;
@@ -285,55 +344,72 @@ __global__ __launch_bounds__(128 * DG) void k_blind_rotate64(DevParams P, const 
                 }
             }
         }
-        __syncthreads();
-        ntt_forward_wave<LOGN, false>(dct + wave * NP, tw, lane, Q, P.mu64);
-        __syncthreads();
+        BCE_PROF_MARK(0);
+        block_sync_lds();
+        BCE_PROF_MARK(1);
+        ntt_forward_wave<LOGN, false>(dct + wave * NP, tw, lane_v, Q, P.mu64);
+        BCE_PROF_MARK(2);
+        block_sync_lds();
+        BCE_PROF_MARK(3);
+        if constexpr (NPRE < 1) request(std::integral_constant<u32, 0>{});
+        if constexpr (NPRE < 2 && NBUF >= 2) request(std::integral_constant<u32, 1>{});
+        if constexpr (NBUF >= 3) request(std::integral_constant<u32, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
         const bool odd = ap & 1u;
-        for (u32 item = tid; item < 2u * (N / 2); item += T) {
-            const u32 c = item / (N / 2), p0 = (item % (N / 2)) * 2;
-            const u32 pp = phys(p0);
-            const u64* bp = bk + (size_t)c * N + p0;
-            U128 sp[2] = {{0, 0}, {0, 0}}, sn[2] = {{0, 0}, {0, 0}};
+        auto mac_item = [&](auto kc) {
+            constexpr u32 k = decltype(kc)::value;
+            const u32 item = tid_v + k * T;
+            if (k + 1 < ITEMS || item < 2u * (N / 2)) {
+                const u32 c = item / (N / 2), p0 = (item % (N / 2)) * 2;
+                const u32 pp = phys(p0);
+                U128 sp[2] = {{0, 0}, {0, 0}}, sn[2] = {{0, 0}, {0, 0}};
 #pragma unroll
-            for (u32 l = 0; l < R; ++l) {
-                const ulonglong2 d = *reinterpret_cast<const ulonglong2*>(dct + l * NP + pp);
-                const ulonglong2 kp = *reinterpret_cast<const ulonglong2*>(bp + (size_t)l * 2 * N);
-                mac128(sp[0], d.x, kp.x);
-                mac128(sp[1], d.y, kp.y);
-                if constexpr (!AP) {
-                    const ulonglong2 kn = *reinterpret_cast<const ulonglong2*>(bp + rgsw + (size_t)l * 2 * N);
-                    mac128(sn[0], d.x, kn.x);
-                    mac128(sn[1], d.y, kn.y);
+                for (u32 l = 0; l < R; ++l) {
+                    const ulonglong2 d = *reinterpret_cast<const ulonglong2*>(dct + l * NP + pp);
+                    const ulonglong2 kp = kb[k % NBUF][l];
+                    mac128(sp[0], d.x, kp.x);
+                    mac128(sp[1], d.y, kp.y);
+                    if constexpr (!AP) {
+                        const ulonglong2 kn = kb[k % NBUF][R + l];
+                        mac128(sn[0], d.x, kn.x);
+                        mac128(sn[1], d.y, kn.y);
+                    }
                 }
-            }
-            u64 a[2];
-            if constexpr (AP) {
-                a[0] = reduce128(sp[0], Q, P.c64, P.mu64);
-                a[1] = reduce128(sp[1], Q, P.c64, P.mu64);
-            } else {
-                // positions p0, p0+1: brv(p0+1) = brv(p0) + N/2, so the monomials differ by psi^(N a') = (-1)^a'
-                const u32 k0 = __brev(p0) >> (32 - LOGN);
-                const u32 ex = ((2 * k0 + 1) * ap) & (2 * N - 1);
-                u64 mp[2], mn[2];
-                mp[0] = psi_pow<LOGN>(tw, ex, Q);
-                mn[0] = psi_pow<LOGN>(tw, (2 * N - ex) & (2 * N - 1), Q);
-                mp[1] = odd ? Q - mp[0] : mp[0];
-                mn[1] = odd ? Q - mn[0] : mn[0];
-                const ulonglong2 av2 = *reinterpret_cast<const ulonglong2*>(acc + c * NP + pp);
-                const u64 old[2] = {av2.x, av2.y};
+                __builtin_amdgcn_sched_barrier(0);  // keep the pipeline depth: do not hoist later requests above this point
+                request(std::integral_constant<u32, k + NBUF>{});  // this item's buffer is free again
+                __builtin_amdgcn_sched_barrier(0);
+                u64 a[2];
+                if constexpr (AP) {
+                    a[0] = reduce128(sp[0], Q, P.c64, P.mu64);
+                    a[1] = reduce128(sp[1], Q, P.c64, P.mu64);
+                } else {
+                    // positions p0, p0+1: brv(p0+1) = brv(p0) + N/2, so the monomials differ by psi^(N a') = (-1)^a'
+                    const u32 k0 = __brev(p0) >> (32 - LOGN);
+                    const u32 ex = ((2 * k0 + 1) * ap) & (2 * N - 1);
+                    u64 mp[2], mn[2];
+                    mp[0] = psi_pow<LOGN>(tw, ex, Q);
+                    mn[0] = psi_pow<LOGN>(tw, (2 * N - ex) & (2 * N - 1), Q);
+                    mp[1] = odd ? Q - mp[0] : mp[0];
+                    mn[1] = odd ? Q - mn[0] : mn[0];
+                    const ulonglong2 av2 = *reinterpret_cast<const ulonglong2*>(acc + c * NP + pp);
+                    const u64 old[2] = {av2.x, av2.y};
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const u64 rp = reduce128(sp[e], Q, P.c64, P.mu64), rn = reduce128(sn[e], Q, P.c64, P.mu64);
-                    U128 t = {0, 0};
-                    mac128(t, rp, mp[e] - 1);
-                    mac128(t, rn, mn[e] - 1);
-                    add128(t, old[e]);
-                    a[e] = reduce128(t, Q, P.c64, P.mu64);
+                    for (int e = 0; e < 2; ++e) {
+                        const u64 rp = reduce128(sp[e], Q, P.c64, P.mu64), rn = reduce128(sn[e], Q, P.c64, P.mu64);
+                        U128 t = {0, 0};
+                        mac128(t, rp, mp[e] - 1);
+                        mac128(t, rn, mn[e] - 1);
+                        add128(t, old[e]);
+                        a[e] = reduce128(t, Q, P.c64, P.mu64);
+                    }
                 }
+                *reinterpret_cast<ulonglong2*>(acc + c * NP + pp) = make_ulonglong2(a[0], a[1]);
             }
-            *reinterpret_cast<ulonglong2*>(acc + c * NP + pp) = make_ulonglong2(a[0], a[1]);
-        }
-        __syncthreads();
+        };
+        for_each_index(mac_item, std::make_integer_sequence<u32, ITEMS>{});
+        BCE_PROF_MARK(4);
+        block_sync_lds();
+        BCE_PROF_MARK(5);
     }
     if (wave < 2) {
         u64 x[E];
@@ -446,3 +522,14 @@ hipError_t launch_pointwise_mac64(const DevParams& P, u64* b, const u64* a, cons
 }
 
 }  // namespace bce
+
+#ifdef BCE_PHASE_PROF
+extern "C" int bce_debug_phase_prof64(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bce::g_phase_prof64), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(bce::g_phase_prof64), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -2,7 +2,7 @@
 
 Rebuilds libbce_amd.so IN THE SCRATCH COPY with -DBCE_PHASE_PROF (the committed build never defines
 it), runs batched STD128_OPT/GINX NAND bootstraps and prints, for workgroup 0, the cycles its thread 0
-spent in each barrier-delimited phase.  Usage: python tools/phase_prof.py [batch ...]
+spent in each barrier-delimited phase.  Usage: python tools/phase_prof.py [STD192|STD192_AP] [batch ...]
 """
 import ctypes as C
 import importlib
@@ -23,8 +23,13 @@ NAMES = ["phase 1 (thread 0: loads issue, inverse NTT, digits)", "wait barrier 1
 
 
 def main():
-    batches = [int(x) for x in sys.argv[1:]] or [1, 256]
-    c = bce.BinFHEContext(bce.STD128_OPT, bce.GINX)
+    args = sys.argv[1:]
+    ps, method, getter = "STD128_OPT", "GINX", lib.bce_debug_phase_prof
+    if args and args[0] in ("STD192", "STD192_AP"):   # 64-bit modulus kernel (kernels64.hip)
+        ps, method, getter = "STD192", ("AP" if args[0].endswith("AP") else "GINX"), lib.bce_debug_phase_prof64
+        args = args[1:]
+    batches = [int(x) for x in args] or [1, 256]
+    c = bce.BinFHEContext(getattr(bce, ps), getattr(bce, method))
     c.KeyGen(42)
     nmax = max(batches)
     c.pool_reserve(3 * nmax)
@@ -35,11 +40,11 @@ def main():
         descs = bce.make_descs([(bce.NAND, 2 * i, 2 * i + 1, 2 * nmax + i) for i in range(nb)])
         c.EvalGates(descs)
         c.synchronize()
-        lib.bce_debug_phase_prof(out, 1)
+        getter(out, 1)
         c.timing_reset()
         c.EvalGates(descs)
         c.synchronize()
-        lib.bce_debug_phase_prof(out, 1)
+        getter(out, 1)
         t = c.timing()
         tot = float(sum(out[:6]))
         print("batch %d: blind_rotate %.2f ms, workgroup 0 total %.0f cycles" % (nb, t["blind_rotate_ms"], tot))
