@@ -77,6 +77,8 @@ struct bce_ctx {
     // work buffers
     void* d_acc = nullptr;
     size_t acc_cap = 0;  // bootstraps
+    u64* d_tail_partial = nullptr;  // partial key-switch sums (kernels.hip, k_tail_gather)
+    size_t tail_cap = 0;            // u64 words
     static constexpr int kRing = 4;
     bce_gate_desc* d_descs[kRing] = {nullptr, nullptr, nullptr, nullptr};
     bce_gate_desc* h_descs[kRing] = {nullptr, nullptr, nullptr, nullptr};
@@ -174,6 +176,11 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     P.baseKS = baseKS; P.dKS = c->dKS;
     P.ksk_stride = (n + 1 + 63) & ~63u;
     P.ksk_u16 = c->qKS <= 65536 ? 1 : 0;
+    {
+        const u64 ch = (((u64)1) << 32) / c->qKS;
+        if (ch < 8) { g_create_error = "qKS too large for the key-switch gather (needs qKS <= 2^29)"; return BCE_ERR_ARG; }
+        P.ks_chunk = (u32)std::min<u64>(ch & ~(u64)7, 1u << 20);
+    }
     P.gBits = c->gBits; P.dG = c->dG; P.baseR = baseR; P.dR = c->dR;
     P.method_ap = method == BCE_AP ? 1 : 0;
     P.factor = (u32)(2 * N / q);
@@ -495,7 +502,18 @@ int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances,
         if (dbg_ks) HIP_TRY(c, hipMalloc(&d_ks, nb * (c->n + 1) * sizeof(u32)));
         EventPair e1 = get_events(c, BCE_BR_KERNELS);  // kind >= BCE_BR_KERNELS: tail
         hipEventRecord(e1.a, c->stream);
-        HIP_TRY(c, launch_tail(c->P, dd, (u32)boot.size(), instances, slot_stride, c->d_acc, d_lweN, d_ks, c->stream));
+        {
+            const size_t need = tail_partial_words(c->P, (u32)nb);
+            if (need > c->tail_cap) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (c->d_tail_partial) hipFree(c->d_tail_partial);
+                c->d_tail_partial = nullptr;
+                const size_t cap = std::max(need, c->tail_cap * 2);
+                HIP_TRY(c, hipMalloc(&c->d_tail_partial, cap * sizeof(u64)));
+                c->tail_cap = cap;
+            }
+        }
+        HIP_TRY(c, launch_tail(c->P, dd, (u32)boot.size(), instances, slot_stride, c->d_acc, c->d_tail_partial, d_lweN, d_ks, c->stream));
         hipEventRecord(e1.b, c->stream);
         c->pending.push_back(e1);
         hipEventRecord(c->ring_ev[slot], c->stream);
@@ -562,7 +580,7 @@ void bce_ctx_destroy(bce_ctx* c) {
         if (c->h_descs[i]) hipHostFree(c->h_descs[i]);
         if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
     }
-    hipFree(c->d_twf); hipFree(c->d_psi); hipFree(c->d_tw64); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc);
+    hipFree(c->d_twf); hipFree(c->d_psi); hipFree(c->d_tw64); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc); hipFree(c->d_tail_partial);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }

@@ -20,6 +20,7 @@
 // in LDS with 4 pad words per 64 so that all three access patterns are bank-conflict free.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <utility>
 
 #include "kernels.hpp"
@@ -1135,81 +1136,175 @@ __device__ __forceinline__ u32 round_qQ(u64 v, u32 q, u64 Qfrom) {
     return (u32)(r >= q ? r - q : r);
 }
 
-// KT = key-switch key element type, ACC = its accumulator, AW = accumulator word of the blind rotation
-template <typename KT, typename ACC, typename AW>
-__global__ __launch_bounds__(256) void k_tail(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
-                                              u32 slot_stride, const AW* __restrict__ acc_in,
-                                              u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
+// The tail runs as two kernels.
+//   k_tail_gather: grid = bootstraps x S.  Workgroup (boot, s) owns the coefficients i in [s N/S, (s+1) N/S):
+//     transpose + ModSwitch(Q -> qKS) of those, digit decomposition to key-switch row numbers in LDS, then the
+//     row gather  sum_rows K[row][0..n]  for its N dKS / S rows.  A lane reads 16 BYTES of a row per load (8 u16 or
+//     4 u32 elements; the padded row stride keeps the last load in bounds), 64..256 lanes cover a row and the
+//     remaining waves take other rows -- one element per lane (the first version) needed 8x the load
+//     instructions and kept 8x fewer bytes in flight.  S > 1 spreads one bootstrap over several CUs when the
+//     launch is small.  Partial sums (u64) go to `partial[boot][s][0..n]`.
+//   k_tail_finish: grid = bootstraps.  Sums the S partials, reduces mod qKS, subtracts from (0, b) and applies
+//     ModSwitch(qKS -> q) into the pool.
+// KT = key-switch key element type (u16 when qKS <= 2^16), AW = accumulator word of the blind rotation.
+template <typename KT, typename AW>
+__global__ __launch_bounds__(256) void k_tail_gather(DevParams P, u32 S, const AW* __restrict__ acc_in,
+                                                     u64* __restrict__ partial, u32* __restrict__ dbg_lweN) {
     extern __shared__ __align__(16) u32 smem[];
+    constexpr u32 VW = 16 / sizeof(KT);  // elements per 16-byte load
     const u32 N = P.N, n = P.n, qKS = P.qKS, B = P.baseKS, D = P.dKS;
     const u64 Q = sizeof(AW) == 8 ? P.Q64 : (u64)P.Q;
-    const u64 Q8p1 = sizeof(AW) == 8 ? P.Q8p1_64 : (u64)P.Q8p1;
-    u32* rowidx = smem;  // [N*D] row number (i*B + digit)*D + j
-    __shared__ u32 s_b;
-    const u32 tid = threadIdx.x, T = blockDim.x;
-    const AW* a0 = acc_in + (size_t)blockIdx.x * 2 * N;
-    const AW* a1 = a0 + N;
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 boot = blockIdx.x / S, s = blockIdx.x - boot * S;
+    const u32 ni = N / S, i0 = s * ni, LR = ni * D;  // coefficients / rows of this workgroup
+    u32* rowidx = smem;                                   // [LR] row number (i*B + digit)*D + j
+    u64* red = reinterpret_cast<u64*>(smem + ((LR + 3) & ~3u));  // [slices][Gv*VW] or [256] (scalar pass)
+    const AW* a0 = acc_in + (size_t)boot * 2 * N;
 
     // Transpose (X -> X^-1) of acc[0]: a'_0 = a_0, a'_{N-i} = -a_i ; then ModSwitch(Q -> qKS)
-    for (u32 i = tid; i < N; i += T) {
-        u64 src = (i == 0) ? a0[0] : a0[N - i];
-        u64 v = (i == 0) ? src : (src ? Q - src : 0);
+    for (u32 ii = tid; ii < ni; ii += 256) {
+        const u32 i = i0 + ii;
+        const u64 src = (i == 0) ? a0[0] : a0[N - i];
+        const u64 v = (i == 0) ? src : (src ? Q - src : 0);
         u32 at = round_qQ(v, qKS, Q);
-        if (dbg_lweN) dbg_lweN[(size_t)blockIdx.x * (N + 1) + i] = at;
+        if (dbg_lweN) dbg_lweN[(size_t)boot * (N + 1) + i] = at;
         for (u32 j = 0; j < D; ++j) {
-            rowidx[i * D + j] = (i * B + at % B) * D + j;
+            rowidx[ii * D + j] = (i * B + at % B) * D + j;
             at /= B;
         }
     }
-    if (tid == 0) {
-        u64 b = (u64)a1[0] + Q8p1;
-        b = b >= Q ? b - Q : b;
-        u32 bs = round_qQ(b, qKS, Q);
-        s_b = bs;
-        if (dbg_lweN) dbg_lweN[(size_t)blockIdx.x * (N + 1) + N] = bs;
-    }
     __syncthreads();
 
-    // KeySwitch: a' = -sum_rows A[row], b' = b - sum_rows B[row]   (mod qKS)
-    const KT* ksk = reinterpret_cast<const KT*>(P.ksk);
-    const u32 rows = N * D;
-    const bce_gate_desc g = descs[blockIdx.x % n_desc];
-    u32* out = P.pool + (size_t)(g.out + (blockIdx.x / n_desc) * slot_stride) * P.pool_stride;
-    for (u32 k = tid; k <= n; k += T) {
-        // row gather: 16 independent loads in flight per thread (the loop is latency-bound otherwise)
-        constexpr u32 U = 16;
-        ACC acc[U];
+    const KT* __restrict__ ksk = reinterpret_cast<const KT*>(P.ksk);
+    const u32 G = (n + VW) / VW;                 // 16-byte groups holding elements 0..n
+    const u32 Gv = G < 256 ? G : 256;            // groups of the vector pass (one per lane of up to 4 waves)
+    const u32 RW = (Gv + 63) / 64, SL = 4 / RW;  // waves per row, row slices per workgroup
+    const u32 slice = wave / RW, group = (wave - slice * RW) * 64 + lane;
+    u64 tot[VW];
 #pragma unroll
-        for (u32 u = 0; u < U; ++u) acc[u] = 0;
-        u32 r = 0;
-        for (; r + U <= rows; r += U) {
+    for (u32 e = 0; e < VW; ++e) tot[e] = 0;
+    if (slice < SL && group < Gv) {
+        // u32 running sums are folded into the u64 totals every CH rows (CH * qKS <= 2^32: no wrap)
+        const u32 CH = P.ks_chunk;
+        constexpr u32 U = 8;  // rows in flight per lane
+        u32 r = slice;
+        while (r < LR) {
+            u32 run[VW];
 #pragma unroll
-            for (u32 u = 0; u < U; ++u) acc[u] += ksk[(size_t)rowidx[r + u] * P.ksk_stride + k];
+            for (u32 e = 0; e < VW; ++e) run[e] = 0;
+            const u32 rend = (LR - r > CH * SL) ? r + CH * SL : LR;
+            for (; r + (U - 1) * SL < rend; r += U * SL) {
+                uint4 v[U];
+#pragma unroll
+                for (u32 u = 0; u < U; ++u) {
+                    const u32 row = __builtin_amdgcn_readfirstlane(rowidx[r + u * SL]);
+                    v[u] = reinterpret_cast<const uint4*>(ksk + (size_t)row * P.ksk_stride)[group];
+                }
+#pragma unroll
+                for (u32 u = 0; u < U; ++u) {
+                    if constexpr (sizeof(KT) == 2) {
+                        run[0] += v[u].x & 0xFFFFu; run[1] += v[u].x >> 16; run[2] += v[u].y & 0xFFFFu; run[3] += v[u].y >> 16;
+                        run[4] += v[u].z & 0xFFFFu; run[5] += v[u].z >> 16; run[6] += v[u].w & 0xFFFFu; run[7] += v[u].w >> 16;
+                    } else {
+                        run[0] += v[u].x; run[1] += v[u].y; run[2] += v[u].z; run[3] += v[u].w;
+                    }
+                }
+            }
+            for (; r < rend; r += SL) {
+                const u32 row = __builtin_amdgcn_readfirstlane(rowidx[r]);
+                const uint4 v = reinterpret_cast<const uint4*>(ksk + (size_t)row * P.ksk_stride)[group];
+                if constexpr (sizeof(KT) == 2) {
+                    run[0] += v.x & 0xFFFFu; run[1] += v.x >> 16; run[2] += v.y & 0xFFFFu; run[3] += v.y >> 16;
+                    run[4] += v.z & 0xFFFFu; run[5] += v.z >> 16; run[6] += v.w & 0xFFFFu; run[7] += v.w >> 16;
+                } else {
+                    run[0] += v.x; run[1] += v.y; run[2] += v.z; run[3] += v.w;
+                }
+            }
+#pragma unroll
+            for (u32 e = 0; e < VW; ++e) tot[e] += run[e];
         }
-        for (; r < rows; ++r) acc[0] += ksk[(size_t)rowidx[r] * P.ksk_stride + k];
-        u64 sum = 0;
 #pragma unroll
-        for (u32 u = 0; u < U; ++u) sum += (u64)acc[u];
-        u32 sm = (u32)(sum % qKS);
-        u32 base = (k == n) ? s_b : 0u;
-        u32 v = base >= sm ? base - sm : base + qKS - sm;
-        if (dbg_ks) dbg_ks[(size_t)blockIdx.x * (n + 1) + k] = v;
+        for (u32 e = 0; e < VW; ++e) red[(size_t)slice * Gv * VW + group * VW + e] = tot[e];
+    }
+    __syncthreads();
+    u64* out = partial + ((size_t)boot * S + s) * (n + 1);
+    for (u32 k = tid; k < Gv * VW && k <= n; k += 256) {
+        u64 sum = 0;
+        for (u32 sl = 0; sl < SL; ++sl) sum += red[(size_t)sl * Gv * VW + k];
+        out[k] = sum;
+    }
+    // elements beyond the vector pass (n + 1 > 256 groups, e.g. the single b column of n = 1024 with u32 rows):
+    // all threads split the rows, one element at a time
+    for (u32 k = Gv * VW; k <= n; ++k) {
+        __syncthreads();
+        u64 sum = 0;
+        for (u32 r = tid; r < LR; r += 256) sum += (u64)ksk[(size_t)rowidx[r] * P.ksk_stride + k];
+        red[tid] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            u64 t = 0;
+            for (u32 i = 0; i < 256; ++i) t += red[i];
+            out[k] = t;
+        }
+    }
+}
+
+template <typename AW>
+__global__ __launch_bounds__(256) void k_tail_finish(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc, u32 slot_stride,
+                                                     u32 S, const AW* __restrict__ acc_in, const u64* __restrict__ partial,
+                                                     u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
+    const u32 N = P.N, n = P.n, qKS = P.qKS;
+    const u64 Q = sizeof(AW) == 8 ? P.Q64 : (u64)P.Q;
+    const u64 Q8p1 = sizeof(AW) == 8 ? P.Q8p1_64 : (u64)P.Q8p1;
+    const u32 boot = blockIdx.x;
+    const bce_gate_desc g = descs[boot % n_desc];
+    u32* out = P.pool + (size_t)(g.out + (boot / n_desc) * slot_stride) * P.pool_stride;
+    const u64* part = partial + (size_t)boot * S * (n + 1);
+    // KeySwitch: a' = -sum_rows A[row], b' = b - sum_rows B[row]   (mod qKS), b = acc[1][0] + Q/8 + 1 mod-switched
+    for (u32 k = threadIdx.x; k <= n; k += 256) {
+        u64 sum = 0;
+        for (u32 s = 0; s < S; ++s) sum += part[(size_t)s * (n + 1) + k];
+        const u32 sm = (u32)(sum % qKS);
+        u32 base = 0;
+        if (k == n) {
+            u64 b = (u64)acc_in[(size_t)boot * 2 * N + N] + Q8p1;
+            b = b >= Q ? b - Q : b;
+            base = round_qQ(b, qKS, Q);
+            if (dbg_lweN) dbg_lweN[(size_t)boot * (N + 1) + N] = base;
+        }
+        const u32 v = base >= sm ? base - sm : base + qKS - sm;
+        if (dbg_ks) dbg_ks[(size_t)boot * (n + 1) + k] = v;
         out[k] = round_qQ(v, P.q, qKS);  // ModSwitch(qKS -> q)
     }
 }
 
+u32 tail_split(const DevParams& P, u32 boots) {
+    // spread a bootstrap's rows over S workgroups while the launch has fewer than ~4 workgroups per CU
+    u32 S = 1;
+    while (S < 16 && boots * S * 2 <= 4 * P.cu_count && P.N / (S * 2) >= 64) S *= 2;
+    return S;
+}
+size_t tail_partial_words(const DevParams& P, u32 boots) { return (size_t)boots * tail_split(P, boots) * (P.n + 1); }
+
 hipError_t launch_tail(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
-                       const void* acc_in, u32* dbg_lweN, u32* dbg_ks, hipStream_t s) {
-    const dim3 grid(n_desc * instances), block(256);
-    const size_t lds = (size_t)P.N * P.dKS * sizeof(u32);
+                       const void* acc_in, u64* partial, u32* dbg_lweN, u32* dbg_ks, hipStream_t s) {
+    const u32 boots = n_desc * instances, S = tail_split(P, boots);
+    const dim3 grid(boots * S), block(256);
+    const u32 VW = P.ksk_u16 ? 8 : 4, G = (P.n + VW) / VW, Gv = G < 256 ? G : 256, RW = (Gv + 63) / 64, SL = 4 / RW;
+    const size_t LR = (size_t)P.N / S * P.dKS;
+    const size_t red_words = std::max<size_t>((size_t)SL * Gv * VW, 256);
+    const size_t lds = ((LR + 3) & ~(size_t)3) * sizeof(u32) + red_words * sizeof(u64);
     if (P.is64) {
         const u64* a = static_cast<const u64*>(acc_in);
-        if (P.ksk_u16) hipLaunchKernelGGL((k_tail<uint16_t, u32, u64>), grid, block, lds, s, P, d, n_desc, slot_stride, a, dbg_lweN, dbg_ks);
-        else hipLaunchKernelGGL((k_tail<u32, u64, u64>), grid, block, lds, s, P, d, n_desc, slot_stride, a, dbg_lweN, dbg_ks);
+        if (P.ksk_u16) hipLaunchKernelGGL((k_tail_gather<uint16_t, u64>), grid, block, lds, s, P, S, a, partial, dbg_lweN);
+        else hipLaunchKernelGGL((k_tail_gather<u32, u64>), grid, block, lds, s, P, S, a, partial, dbg_lweN);
+        hipLaunchKernelGGL((k_tail_finish<u64>), dim3(boots), block, 0, s, P, d, n_desc, slot_stride, S, a, partial, dbg_lweN, dbg_ks);
     } else {
         const u32* a = static_cast<const u32*>(acc_in);
-        if (P.ksk_u16) hipLaunchKernelGGL((k_tail<uint16_t, u32, u32>), grid, block, lds, s, P, d, n_desc, slot_stride, a, dbg_lweN, dbg_ks);
-        else hipLaunchKernelGGL((k_tail<u32, u64, u32>), grid, block, lds, s, P, d, n_desc, slot_stride, a, dbg_lweN, dbg_ks);
+        if (P.ksk_u16) hipLaunchKernelGGL((k_tail_gather<uint16_t, u32>), grid, block, lds, s, P, S, a, partial, dbg_lweN);
+        else hipLaunchKernelGGL((k_tail_gather<u32, u32>), grid, block, lds, s, P, S, a, partial, dbg_lweN);
+        hipLaunchKernelGGL((k_tail_finish<u32>), dim3(boots), block, 0, s, P, d, n_desc, slot_stride, S, a, partial, dbg_lweN, dbg_ks);
     }
     return hipGetLastError();
 }

@@ -20,6 +20,7 @@ struct DevParams {
     u32 baseKS, dKS;
     u32 ksk_stride;   // elements per KSK row (>= n+1, padded)
     u32 ksk_u16;      // 1: rows are uint16_t, 0: uint32_t
+    u32 ks_chunk;     // rows whose elements can be summed in 32 bits: floor(2^32 / qKS), a multiple of 8, >= 8
     u32 gBits, dG;    // gadget: base 2^gBits, dG digits; R = 2*dG RGSW rows
     u32 baseR, dR;    // AP only
     u32 method_ap;    // 1: AP/DM accumulator, 0: GINX/CGGI
@@ -64,8 +65,11 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d_descs,
 
 // extract + ModSwitch(Q->qKS) + KeySwitch + ModSwitch(qKS->q) -> pool[out]
 // dbg_lweN: u32 [n_boot][N+1] or null; dbg_ks: u32 [n_boot][n+1] or null
+// partial: device scratch of tail_partial_words(P, n_desc * instances) u64 words (partial key-switch sums)
+size_t tail_partial_words(const DevParams& P, u32 boots);
 hipError_t launch_tail(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances, u32 slot_stride,
-                       const void* acc_in /* u32 or u64 words by P.is64 */, u32* dbg_lweN, u32* dbg_ks, hipStream_t s);
+                       const void* acc_in /* u32 or u64 words by P.is64 */, u64* partial, u32* dbg_lweN, u32* dbg_ks,
+                       hipStream_t s);
 
 // 64-bit-modulus counterparts (kernels64.hip)
 size_t blind_rotate64_lds_bytes(const DevParams& P);
