@@ -63,6 +63,7 @@ struct bce_ctx {
     u32* d_psi = nullptr;
     void* d_bsk = nullptr;       // u32 words (Q < 2^28) or u64 words (is64)
     ulonglong2* d_tw64 = nullptr;
+    double2* d_tw64d = nullptr;   // (w, w / Q) for the double-precision formulation
     bool is64 = false;
     size_t wbytes = 4;
     void* d_ksk = nullptr;
@@ -250,9 +251,30 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         P.tw64 = c->d_tw64;
         if (blind_rotate64_lds_bytes(P) > 160 * 1024) { g_create_error = "64-bit path: polynomials do not fit the 160 KiB LDS"; return BCE_ERR_UNSUPPORTED; }
         P.lazy = 1;
+        // double-precision formulation (kernels64.hip, namespace wd): exact for Q < 2^39; BCE_FP64=0 keeps the
+        // integer kernel (development / parity knob)
+        const char* fp = std::getenv("BCE_FP64");
+        P.fp64 = (Q < (1ull << 39) && !(fp && fp[0] == '0')) ? 1 : 0;
+        P.Qd = (double)Q;
+        P.invQd = 1.0 / (double)Q;
+        P.Ninvd = (double)ninv;
+        P.Ninvd_q = (double)ninv / (double)Q;
+        std::vector<double2> twd(N);
+        for (u32 i = 0; i < N; ++i) twd[i] = make_double2((double)tw64[i].x, (double)tw64[i].x / (double)Q);
+        if (hipMalloc(&c->d_tw64d, sizeof(double2) * N) != hipSuccess) { g_create_error = "hipMalloc(twiddles64d) failed"; return BCE_ERR_HIP; }
+        hipMemcpy(c->d_tw64d, twd.data(), sizeof(double2) * N, hipMemcpyHostToDevice);
+        P.tw64d = c->d_tw64d;
     }
     P.pool_stride = n + 1;
     *out = c.release();
+    return BCE_OK;
+}
+
+// the double-precision 64-bit kernels read the evaluation-form key words as IEEE doubles (exact, Q < 2^39)
+int bsk_words_to_kernel_layout(bce_ctx* c) {
+    if (!c->is64 || !c->P.fp64) return BCE_OK;
+    HIP_TRY(c, launch_words_u64_f64(static_cast<u64*>(c->d_bsk), (size_t)c->bsk_polys * c->N, 1, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return BCE_OK;
 }
 
@@ -580,7 +602,7 @@ void bce_ctx_destroy(bce_ctx* c) {
         if (c->h_descs[i]) hipHostFree(c->h_descs[i]);
         if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
     }
-    hipFree(c->d_twf); hipFree(c->d_psi); hipFree(c->d_tw64); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc); hipFree(c->d_tail_partial);
+    hipFree(c->d_twf); hipFree(c->d_psi); hipFree(c->d_tw64); hipFree(c->d_tw64d); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc); hipFree(c->d_tail_partial);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -647,6 +669,7 @@ int bce_keygen(bce_ctx* c, const uint8_t seed[32]) {
     }
 
     rc = c->is64 ? keygen_bsk<u64>(c, gauss) : keygen_bsk<u32>(c, gauss);
+    if (!rc) rc = bsk_words_to_kernel_layout(c);
     if (rc) return rc;
     c->have_keys = true;
     return BCE_OK;
@@ -678,6 +701,7 @@ int bce_import_keys(bce_ctx* c, const int32_t* s, const int32_t* z, const uint64
         }
         rc = dev_ntt(c, c->d_bsk, bsk_words / c->N, 0);
         if (rc) return rc;
+        if ((rc = bsk_words_to_kernel_layout(c))) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     rc = upload_ksk(c, ksk);
@@ -706,6 +730,7 @@ int bce_export_bsk(bce_ctx* c, uint64_t* bsk) {
         const u64 cnt = std::min(chunk_polys, words / c->N - p0), w = cnt * c->N;
         const char* src = static_cast<const char*>(c->d_bsk) + p0 * c->N * c->wbytes;
         HIP_TRY(c, hipMemcpyAsync(d_tmp, src, w * c->wbytes, hipMemcpyDeviceToDevice, c->stream));
+        if (c->P.fp64) HIP_TRY(c, launch_words_u64_f64(static_cast<u64*>(d_tmp), w, 0, c->stream));  // doubles -> u64 words
         int rc = dev_ntt(c, d_tmp, cnt, 1);
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));

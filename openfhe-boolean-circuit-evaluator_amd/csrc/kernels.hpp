@@ -50,6 +50,12 @@ struct DevParams {
     u64 Ninv64, Ninv64_s;
     const ulonglong2* tw64;  // [N] (psi^brv(i), floor(. * 2^64 / Q))
     const u64* bsk64;
+    // double-precision formulation of the 64-bit path (kernels64.hip, namespace wd), used when fp64 != 0 (Q < 2^39):
+    // the key words at bsk64 are then IEEE doubles
+    u32 fp64;
+    double Qd, invQd;          // Q, 1/Q
+    double Ninvd, Ninvd_q;     // N^-1 mod Q and N^-1 / Q
+    const double2* tw64d;      // [N] (psi^brv(i), psi^brv(i) / Q)
     const void* ksk;    // [N][baseKS][dKS][ksk_stride]
     u32* pool;          // [slots][pool_stride]
     u32 pool_stride;
@@ -76,6 +82,8 @@ size_t blind_rotate64_lds_bytes(const DevParams& P);
 hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances,
                                  u32 slot_stride, u64* acc_out, hipStream_t s);
 hipError_t launch_ntt_batch64(const DevParams& P, u64* polys, u32 count, int inverse, hipStream_t s);
+// key words u64 <-> IEEE double in place (layout of the double-precision formulation)
+hipError_t launch_words_u64_f64(u64* words, size_t count, int to_double, hipStream_t s);
 hipError_t launch_pointwise_mac64(const DevParams& P, u64* b, const u64* a, const u64* z, u32 count, u32 b_step,
                                   hipStream_t s);
 

@@ -466,6 +466,378 @@ __global__ void k_pointwise_mac64(DevParams P, u64* __restrict__ b, const u64* _
 
 }  // namespace w64
 
+// =======================================================================================
+// Double-precision formulation of the same blind rotation (Q < 2^39, selected by DevParams::fp64)
+// =======================================================================================
+// A 64-bit Shoup butterfly costs ~33 integer VALU instructions (three 64x64 multiplies built from 32-bit
+// ones plus carries); gfx950 runs fp64 FMA at the 32-bit integer multiply rate, and with exact-integer
+// doubles a modular product is 6 instructions:
+//     h = y*w;  l = fma(y, w, -h);  q = rint(y * (w/Q));  r = fma(-q, Q, h) + l        (r = y*w - q*Q exactly)
+// h + l is the exact product (fma), q is within 0.5 + 2^-4 of y*w/Q for |y| < 2^49, so h - q*Q is an integer
+// below 2^38 in magnitude and therefore exact, as is the final sum: |r| <= 0.57 Q and r = y*w (mod Q).
+// Every value in LDS / registers is an integer held in a double, |value| < 2^53 always:
+//   forward: T = modmul(Y, w), X' = X + T, Y' = X - T         -> grows by < 0.57 Q per stage (< 7 Q after 11)
+//   inverse: X' = X + Y, Y' = modmul(Y - X, -w)               -> sums grow 2x per stage, < 2^11 * 0.6 Q < 2^49;
+//            no intermediate reduction at all, one modmul by N^-1 at the end
+// so results are the same residues as the integer kernel's; the final accumulator is mapped to [0, Q) as u64,
+// and the digit decomposition first maps to the reference's representative in [-(Q+1)/2, (Q-3)/2]
+// (SignedDigitDecompose centres the canonical value with `x < Q/2`).  Key rows are stored as doubles in HBM
+// (converted once after key generation / import).  Compiled with -ffp-contract=off: products are never fused
+// except where fma() is written.
+namespace wd {
+using w64::Cfg;
+using w64::phys;
+using w64::elem_j;
+using w64::wave_sync;
+using w64::block_sync_lds;
+using w64::for_each_index;
+using w64::gate_const;
+
+__device__ __forceinline__ double modmul_q(double y, double w, double wq, double Q) {  // wq = w / Q (rounded)
+    const double h = y * w;
+    const double l = fma(y, w, -h);
+    const double q = rint(y * wq);
+    return fma(-q, Q, h) + l;
+}
+__device__ __forceinline__ double modmul(double y, double w, double invQ, double Q) {
+    const double h = y * w;
+    const double l = fma(y, w, -h);
+    const double q = rint(h * invQ);
+    return fma(-q, Q, h) + l;
+}
+__device__ __forceinline__ double modred(double s, double invQ, double Q) { return fma(-rint(s * invQ), Q, s); }
+
+template <int LOGN, int LO>
+__device__ __forceinline__ void load_pass(const double* poly, u32 lane, double (&x)[Cfg<LOGN>::E]) {
+#pragma unroll
+    for (int r = 0; r < Cfg<LOGN>::E; ++r) x[r] = poly[phys(elem_j<LOGN, LO>(lane, r))];
+}
+template <int LOGN, int LO>
+__device__ __forceinline__ void store_pass(double* poly, u32 lane, const double (&x)[Cfg<LOGN>::E]) {
+#pragma unroll
+    for (int r = 0; r < Cfg<LOGN>::E; ++r) poly[phys(elem_j<LOGN, LO>(lane, r))] = x[r];
+}
+template <int LOGN, int LO, int B>
+__device__ __forceinline__ void fwd_stage(double (&x)[Cfg<LOGN>::E], u32 lane, const double2* __restrict__ tw, double Q) {
+    constexpr int LE = Cfg<LOGN>::LE, E = Cfg<LOGN>::E, rb = B - LO;
+    constexpr u32 m = 1u << (LOGN - 1 - B);
+    const u32 hi = (lane >> LO) << (LO + LE - B - 1);
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        if (r & (1 << rb)) continue;
+        const double2 w = tw[m + (hi | (u32)(r >> (rb + 1)))];
+        const double X = x[r];
+        const double T = modmul_q(x[r | (1 << rb)], w.x, w.y, Q);
+        x[r] = X + T;
+        x[r | (1 << rb)] = X - T;
+    }
+}
+// psi^-k = -psi^(N-k): entry (2m-1) - i of the forward table, the sign goes into the operand (Y - X)
+template <int LOGN, int LO, int B>
+__device__ __forceinline__ void inv_stage(double (&x)[Cfg<LOGN>::E], u32 lane, const double2* __restrict__ tw, double Q) {
+    constexpr int LE = Cfg<LOGN>::LE, E = Cfg<LOGN>::E, rb = B - LO;
+    constexpr u32 m = 1u << (LOGN - 1 - B);
+    const u32 hi = (lane >> LO) << (LO + LE - B - 1);
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        if (r & (1 << rb)) continue;
+        const double2 f = tw[(2 * m - 1) - (hi | (u32)(r >> (rb + 1)))];
+        const double X = x[r], Y = x[r | (1 << rb)];
+        x[r] = X + Y;
+        x[r | (1 << rb)] = modmul_q(Y - X, f.x, f.y, Q);
+    }
+}
+template <int LOGN, int LO, int BHI, int BLO>
+__device__ __forceinline__ void fwd_stages(double (&x)[Cfg<LOGN>::E], u32 lane, const double2* tw, double Q) {
+    if constexpr (BHI >= BLO) {
+        fwd_stage<LOGN, LO, BHI>(x, lane, tw, Q);
+        fwd_stages<LOGN, LO, BHI - 1, BLO>(x, lane, tw, Q);
+    }
+}
+template <int LOGN, int LO, int BLO, int BHI>
+__device__ __forceinline__ void inv_stages(double (&x)[Cfg<LOGN>::E], u32 lane, const double2* tw, double Q) {
+    if constexpr (BLO <= BHI) {
+        inv_stage<LOGN, LO, BLO>(x, lane, tw, Q);
+        inv_stages<LOGN, LO, BLO + 1, BHI>(x, lane, tw, Q);
+    }
+}
+// forward NTT by one wave in LDS; |input| <= Q, |output| < 7 Q, bit-reversed order
+template <int LOGN>
+__device__ __forceinline__ void ntt_forward_wave(double* poly, const double2* tw, u32 lane, double Q) {
+    using C = Cfg<LOGN>;
+    double x[C::E];
+    load_pass<LOGN, 6>(poly, lane, x);
+    fwd_stages<LOGN, 6, LOGN - 1, 6>(x, lane, tw, Q);
+    store_pass<LOGN, 6>(poly, lane, x);
+    wave_sync();
+    load_pass<LOGN, C::F2LO>(poly, lane, x);
+    fwd_stages<LOGN, C::F2LO, 5, C::F2LO>(x, lane, tw, Q);
+    if constexpr (C::F2LO > 0) {
+        store_pass<LOGN, C::F2LO>(poly, lane, x);
+        wave_sync();
+        load_pass<LOGN, 0>(poly, lane, x);
+        fwd_stages<LOGN, 0, C::F2LO - 1, 0>(x, lane, tw, Q);
+    }
+    store_pass<LOGN, 0>(poly, lane, x);
+    wave_sync();
+}
+// inverse NTT by one wave; |src| <= 0.6 Q bit-reversed; coefficient j = (r << 6) | lane in x[r], |x| <= 0.57 Q
+template <int LOGN>
+__device__ __forceinline__ void ntt_inverse_wave(const double* src, double* tmp, const double2* tw, u32 lane, double Q,
+                                                 double2 ninv, double (&x)[Cfg<LOGN>::E]) {
+    using C = Cfg<LOGN>;
+    constexpr int LE = C::LE;
+    load_pass<LOGN, 0>(src, lane, x);
+    inv_stages<LOGN, 0, 0, LE - 1>(x, lane, tw, Q);
+    store_pass<LOGN, 0>(tmp, lane, x);
+    wave_sync();
+    load_pass<LOGN, LE>(tmp, lane, x);
+    inv_stages<LOGN, LE, LE, 2 * LE - 1>(x, lane, tw, Q);
+    store_pass<LOGN, LE>(tmp, lane, x);
+    wave_sync();
+    load_pass<LOGN, 6>(tmp, lane, x);
+    inv_stages<LOGN, 6, 2 * LE, LOGN - 1>(x, lane, tw, Q);
+#pragma unroll
+    for (int r = 0; r < C::E; ++r) x[r] = modmul_q(x[r], ninv.x, ninv.y, Q);
+}
+template <int LOGN>
+__device__ __forceinline__ double psi_pow(const double2* tw, u32 e, double Q) {
+    constexpr u32 N = 1u << LOGN;
+    const double v = tw[__brev(e & (N - 1)) >> (32 - LOGN)].x;
+    return (e & N) ? Q - v : v;
+}
+__device__ __forceinline__ double2 key_row(__amdgpu_buffer_rsrc_t rsrc, u32 voff, u32 soff) {
+    const ulonglong2 v = w64::key_row(rsrc, voff, soff);
+    return make_double2(__longlong_as_double((long long)v.x), __longlong_as_double((long long)v.y));
+}
+
+template <int LOGN, int DG, bool AP, u32 NBUF_ = (AP ? 3 : 2), u32 NPRE_ = (AP ? 2 : 1)>
+__global__ __launch_bounds__(128 * DG) void k_blind_rotate64d(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
+                                                               u32 slot_stride, u64* __restrict__ acc_out) {
+    using C = Cfg<LOGN>;
+    constexpr int N = C::N, NP = C::NP, E = C::E;
+    constexpr u32 R = 2 * DG, T = 64 * R;
+    extern __shared__ __align__(16) double smemd[];
+    double* acc = smemd;          // [2][NP] evaluation form, |value| <= 0.6 Q
+    double* dct = acc + 2 * NP;   // [R][NP]
+    u32* av = reinterpret_cast<u32*>(dct + R * NP);
+    const double2* __restrict__ tw = P.tw64d;
+
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double Q = P.Qd, invQ = P.invQd;
+    const u32 q = P.q, qm = q - 1, n = P.n;
+    const bce_gate_desc g = descs[blockIdx.x % n_desc];
+    const u32 soff = (blockIdx.x / n_desc) * slot_stride;
+    {
+        const u32* in0 = P.pool + (size_t)(g.in0 + soff) * P.pool_stride;
+        const u32* in1 = P.pool + (size_t)(g.in1 + soff) * P.pool_stride;
+        const bool two = g.op <= BCE_XNOR_FAST;
+        for (u32 i = tid; i <= n; i += T) {
+            u32 v0 = in0[i];
+            if (g.neg0) v0 = ((i == n ? (q >> 2) : 0u) - v0) & qm;
+            u32 v = v0;
+            if (two) {
+                u32 v1 = in1[i];
+                if (g.neg1) v1 = ((i == n ? (q >> 2) : 0u) - v1) & qm;
+                v = (g.op == BCE_XOR_FAST || g.op == BCE_XNOR_FAST) ? (2u * (v0 - v1)) & qm : (v0 + v1) & qm;
+            } else if (i == n) {
+                v = (v0 + (q >> 2)) & qm;
+            }
+            av[i] = v;
+        }
+    }
+    __syncthreads();
+    {
+        const u32 b = av[n];
+        const u32 q1 = gate_const(g.op, q), q2 = (q1 + (q >> 1)) & qm;
+        const double pos = (double)P.Q8p1_64, neg = -pos;
+        for (u32 j = tid; j < (u32)N; j += T) {
+            double v = 0.0;
+            if (j % P.factor == 0) {
+                u32 t = (b - j / P.factor) & qm;
+                bool in = (q1 < q2) ? (t >= q1 && t < q2) : !(t >= q2 && t < q1);
+                v = in ? neg : pos;
+            }
+            acc[phys(j)] = 0.0;
+            acc[NP + phys(j)] = v;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) ntt_forward_wave<LOGN>(acc + NP, tw, lane, Q);
+    __syncthreads();
+    for (u32 j = tid; j < (u32)N; j += T) acc[NP + phys(j)] = modred(acc[NP + phys(j)], invQ, Q);
+    __syncthreads();
+
+    const double2 ninv = make_double2(P.Ninvd, P.Ninvd_q);
+    constexpr size_t rgsw = (size_t)R * 2 * N;
+    const double* __restrict__ bsk = reinterpret_cast<const double*>(P.bsk64);
+    // SignedDigitDecompose: representative of the reference (canonical x, `x < Q/2 ? x : x - Q`), closed-form digits
+    const double dlo = -(double)((P.Q64 + 1) / 2), dhi = (double)((P.Q64 - 3) / 2);
+    const double Bd = (double)(1u << P.gBits), invB = 1.0 / Bd, halfB = 0.5 * Bd;
+    double doff = 0.0;
+    {
+        double pw = halfB;
+        for (u32 l = 0; l < (u32)DG; ++l) { doff += pw; pw *= Bd; }
+    }
+    const u32 nsteps = AP ? n * P.dR : n;
+    BCE_PROF_INIT();
+    for (u32 step = 0; step < nsteps; ++step) {
+        u32 ap = 0;
+        const double* bk;
+        if constexpr (!AP) {
+            ap = ((q - av[step]) & qm) * P.factor;
+            if (ap == 0) continue;
+            bk = bsk + (size_t)step * 2 * rgsw;
+        } else {
+            const u32 i = step / P.dR, k = step - i * P.dR;
+            u32 aI = (q - av[i]) & qm;
+            for (u32 t = 0; t < k; ++t) aI /= P.baseR;
+            const u32 a0 = aI % P.baseR;
+            if (a0 == 0) continue;
+            bk = bsk + (((size_t)i * P.baseR + a0) * P.dR + k) * rgsw;
+        }
+        // key rows: same software pipeline as the integer kernel
+        constexpr u32 ITEMS = (2u * (N / 2) + T - 1) / T;
+        constexpr u32 ROWS = AP ? R : 2 * R;
+        constexpr u32 NBUF = NBUF_, NPRE = NPRE_;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double*>(bk), 0, (int)((AP ? 1 : 2) * rgsw * sizeof(double)), 0x00020000);
+        double2 kb[NBUF][ROWS];
+        u32 tid_v = tid, lane_v = lane;
+        asm volatile("" : "+v"(tid_v), "+v"(lane_v));  // keep the address arithmetic inside the step loop
+        auto request = [&](auto kc) {
+            constexpr u32 k = decltype(kc)::value;
+            if constexpr (k < ITEMS) {
+                const u32 item = tid_v + k * T;
+                if (k + 1 < ITEMS || item < 2u * (N / 2)) {
+                    const u32 c = item / (N / 2), p0 = (item % (N / 2)) * 2;
+                    const u32 voff = (c * N + p0) * 8u;
+#pragma unroll
+                    for (u32 l = 0; l < R; ++l) {
+                        kb[k % NBUF][l] = key_row(rsrc, voff, l * (2 * N * 8));
+                        if constexpr (!AP) kb[k % NBUF][R + l] = key_row(rsrc, voff, (u32)(rgsw * 8) + l * (2 * N * 8));
+                    }
+                }
+            }
+        };
+        if constexpr (NPRE >= 1) request(std::integral_constant<u32, 0>{});
+        if constexpr (NPRE >= 2) request(std::integral_constant<u32, 1>{});
+        if (wave < 2) {
+            double x[E];
+            ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, tw, lane_v, Q, ninv, x);
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                double d = x[r];
+                d = d > dhi ? d - Q : d;
+                d = d < dlo ? d + Q : d;
+                double u = d + doff;
+                const u32 pj = phys(((u32)r << 6) | lane_v);
+#pragma unroll
+                for (u32 l = 0; l < (u32)DG; ++l) {
+                    const double t = floor(u * invB);
+                    dct[(2 * l + wave) * NP + pj] = fma(-t, Bd, u) - halfB;  // digit in [-B/2, B/2)
+                    u = t;
+                }
+            }
+        }
+        BCE_PROF_MARK(0);
+        block_sync_lds();
+        BCE_PROF_MARK(1);
+        ntt_forward_wave<LOGN>(dct + wave * NP, tw, lane_v, Q);
+        BCE_PROF_MARK(2);
+        block_sync_lds();
+        BCE_PROF_MARK(3);
+        if constexpr (NPRE < 1) request(std::integral_constant<u32, 0>{});
+        if constexpr (NPRE < 2 && NBUF >= 2) request(std::integral_constant<u32, 1>{});
+        if constexpr (NBUF >= 3) request(std::integral_constant<u32, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        const bool odd = ap & 1u;
+        auto mac_item = [&](auto kc) {
+            constexpr u32 k = decltype(kc)::value;
+            const u32 item = tid_v + k * T;
+            if (k + 1 < ITEMS || item < 2u * (N / 2)) {
+                const u32 c = item / (N / 2), p0 = (item % (N / 2)) * 2;
+                const u32 pp = phys(p0);
+                double sp[2] = {0.0, 0.0}, sn[2] = {0.0, 0.0};
+#pragma unroll
+                for (u32 l = 0; l < R; ++l) {
+                    const double2 d = *reinterpret_cast<const double2*>(dct + l * NP + pp);
+                    const double2 kp = kb[k % NBUF][l];
+                    sp[0] += modmul(d.x, kp.x, invQ, Q);
+                    sp[1] += modmul(d.y, kp.y, invQ, Q);
+                    if constexpr (!AP) {
+                        const double2 kn = kb[k % NBUF][R + l];
+                        sn[0] += modmul(d.x, kn.x, invQ, Q);
+                        sn[1] += modmul(d.y, kn.y, invQ, Q);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                request(std::integral_constant<u32, k + NBUF>{});
+                __builtin_amdgcn_sched_barrier(0);
+                double a[2];
+                if constexpr (AP) {
+                    a[0] = modred(sp[0], invQ, Q);
+                    a[1] = modred(sp[1], invQ, Q);
+                } else {
+                    const u32 k0 = __brev(p0) >> (32 - LOGN);
+                    const u32 ex = ((2 * k0 + 1) * ap) & (2 * N - 1);
+                    double mp[2], mn[2];
+                    mp[0] = psi_pow<LOGN>(tw, ex, Q);
+                    mn[0] = psi_pow<LOGN>(tw, (2 * N - ex) & (2 * N - 1), Q);
+                    mp[1] = odd ? Q - mp[0] : mp[0];
+                    mn[1] = odd ? Q - mn[0] : mn[0];
+                    const double2 old = *reinterpret_cast<const double2*>(acc + c * NP + pp);
+                    const double oldv[2] = {old.x, old.y};
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const double rp = modred(sp[e], invQ, Q), rn = modred(sn[e], invQ, Q);
+                        const double t = modmul(rp, mp[e] - 1.0, invQ, Q) + modmul(rn, mn[e] - 1.0, invQ, Q) + oldv[e];
+                        a[e] = modred(t, invQ, Q);
+                    }
+                }
+                *reinterpret_cast<double2*>(acc + c * NP + pp) = make_double2(a[0], a[1]);
+            }
+        };
+        for_each_index(mac_item, std::make_integer_sequence<u32, ITEMS>{});
+        BCE_PROF_MARK(4);
+        block_sync_lds();
+        BCE_PROF_MARK(5);
+    }
+    if (wave < 2) {
+        double x[E];
+        ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, tw, lane, Q, ninv, x);
+        u64* out = acc_out + ((size_t)blockIdx.x * 2 + wave) * N;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const double v = x[r] < 0.0 ? x[r] + Q : x[r];   // [0, Q), an integer below 2^39
+            const double hi = floor(v * (1.0 / 4294967296.0));
+            out[((u32)r << 6) | lane] = ((u64)(u32)hi << 32) | (u64)(u32)fma(-hi, 4294967296.0, v);
+        }
+    }
+}
+
+// key words u64 <-> double in place (exact: Q < 2^39)
+__global__ void k_words_u64_f64(u64* __restrict__ w, size_t count, int to_double) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        if (to_double) {
+            const u64 v = w[i];
+            const double d = fma((double)(u32)(v >> 32), 4294967296.0, (double)(u32)v);
+            w[i] = (u64)__double_as_longlong(d);
+        } else {
+            const double d = __longlong_as_double((long long)w[i]);
+            const double hi = floor(d * (1.0 / 4294967296.0));
+            w[i] = ((u64)(u32)hi << 32) | (u64)(u32)fma(-hi, 4294967296.0, d);
+        }
+    }
+}
+}  // namespace wd
+
+hipError_t launch_words_u64_f64(u64* words, size_t count, int to_double, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(wd::k_words_u64_f64, dim3(4096), dim3(256), 0, s, words, count, to_double);
+    return hipGetLastError();
+}
+
 size_t blind_rotate64_lds_bytes(const DevParams& P) {
     const size_t N = P.N, NP = N + (N >> 6) * 4, R = 2 * P.dG;
     return (2 + R) * NP * sizeof(u64) + ((P.n + 1 + 3) & ~3u) * sizeof(u32);
@@ -476,7 +848,16 @@ hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32
     using K = void (*)(DevParams, const bce_gate_desc*, u32, u32, u64*);
     const bool ap = P.method_ap != 0;
     K kern = nullptr;
-    if (P.dG == 3) {
+    if (P.fp64 && P.dG == 3) {
+        switch (P.logN) {
+            case 9: kern = ap ? wd::k_blind_rotate64d<9, 3, true> : wd::k_blind_rotate64d<9, 3, false>; break;
+            case 10: kern = ap ? wd::k_blind_rotate64d<10, 3, true> : wd::k_blind_rotate64d<10, 3, false>; break;
+            case 11: kern = ap ? wd::k_blind_rotate64d<11, 3, true> : wd::k_blind_rotate64d<11, 3, false>; break;
+            default: break;
+        }
+    } else if (P.fp64 && P.dG == 4 && P.logN == 9) {
+        kern = ap ? wd::k_blind_rotate64d<9, 4, true> : wd::k_blind_rotate64d<9, 4, false>;
+    } else if (P.dG == 3) {
         switch (P.logN) {
             case 9: kern = ap ? w64::k_blind_rotate64<9, 3, true> : w64::k_blind_rotate64<9, 3, false>; break;
             case 10: kern = ap ? w64::k_blind_rotate64<10, 3, true> : w64::k_blind_rotate64<10, 3, false>; break;

@@ -277,8 +277,12 @@ def _custom64(orc):
     return (16, 512, 512, Q, 1 << 15, 32,    1 << 13, 23)
 
 
+@pytest.mark.parametrize("arith", ["fp64", "int64"])
 @pytest.mark.parametrize("method", ["GINX", "AP"])
-def test_q64_custom_context_bit_exact_stages(bce, orc, method):
+def test_q64_custom_context_bit_exact_stages(bce, orc, method, arith, monkeypatch):
+    """The 64-bit-modulus path has two blind-rotation kernels: exact-integer doubles (default for Q < 2^39) and
+    64-bit integer Shoup arithmetic (BCE_FP64=0); both must match the oracle bit for bit at every stage."""
+    monkeypatch.setenv("BCE_FP64", "1" if arith == "fp64" else "0")
     params = _custom64(orc)
     o = orc.Oracle(method=getattr(orc, method), custom=params)
     o.keygen(31337)
