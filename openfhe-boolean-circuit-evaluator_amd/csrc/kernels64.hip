@@ -611,12 +611,115 @@ __device__ __forceinline__ double2 key_row(__amdgpu_buffer_rsrc_t rsrc, u32 voff
     return make_double2(__longlong_as_double((long long)v.x), __longlong_as_double((long long)v.y));
 }
 
-template <int LOGN, int DG, bool AP, u32 NBUF_ = (AP ? 3 : 2), u32 NPRE_ = (AP ? 2 : 1)>
-__global__ __launch_bounds__(128 * DG) void k_blind_rotate64d(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
+// ---- split inverse transform for N = 2048 (doubles): 4 waves x 64 lanes x 8 coefficients per polynomial ----------
+// Three-stage passes on position bits (0,1,2), (3,4,5), (6,7,8) and a two-stage pass on (9,10); between passes the
+// values go through LDS in REGISTER-MAJOR layouts (register r of thread t at r * stride + t: consecutive lanes,
+// conflict-free stores) whose row strides make the next pass's loads conflict-free too:
+//   e0: 257 (reader lanes vary p[2:0] and p[8:6]),  e1: 264 (reader lanes vary p[5:0]),  e2: 256.
+// No reduction anywhere (see the bounds above); the caller multiplies by N^-1.
+// three Gentleman-Sande stages on the register index bits 0,1,2; twiddles: f0[4] (bit 0), f1[2] (bit 1), f2 (bit 2)
+__device__ __forceinline__ void inv_pass8(double (&x)[8], const double2 (&f0)[4], const double2 (&f1)[2], double2 f2, double Q) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // pairs (2k, 2k+1): index bits above bit 0 = k
+        const double X = x[2 * k], Y = x[2 * k + 1];
+        x[2 * k] = X + Y;
+        x[2 * k + 1] = modmul_q(Y - X, f0[k].x, f0[k].y, Q);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // pairs (r, r+2), r = (k>>1)*4 + (k&1): twiddle by r >> 2
+        const int r = (k >> 1) * 4 + (k & 1);
+        const double X = x[r], Y = x[r + 2];
+        x[r] = X + Y;
+        x[r + 2] = modmul_q(Y - X, f1[k >> 1].x, f1[k >> 1].y, Q);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // pairs (r, r+4)
+        const double X = x[r], Y = x[r + 4];
+        x[r] = X + Y;
+        x[r + 4] = modmul_q(Y - X, f2.x, f2.y, Q);
+    }
+}
+// inverse twiddle of stage B for stage index i: -tw[(2m - 1) - i], m = 2^(LOGN-1-B); the sign sits in the operand
+template <int B>
+__device__ __forceinline__ double2 itw11(const double2* __restrict__ tw, u32 i) {
+    constexpr u32 m = 1u << (10 - B);
+    return tw[(2 * m - 1) - i];
+}
+// acc: evaluation-form polynomial (padded natural layout); bufA / bufB: >= 2112 doubles each; t = thread in the
+// 256-thread group.  Leaves coefficient j = (r << 8) | t in x[r] (before the N^-1 scaling).  4 workgroup barriers;
+// bufA must not be written by anyone until the caller's next barrier (pass 3 reads it).
+__device__ __forceinline__ void split_inverse11(const double* src, double* bufA, double* bufB, const double2* __restrict__ tw,
+                                                u32 t, double Q, double (&x)[8]) {
+    double2 f0[4], f1[2], f2;
+    {   // pass 0: p = 8t + r
+        const double2* sp = reinterpret_cast<const double2*>(src + phys(8 * t));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const double2 v = sp[k]; x[2 * k] = v.x; x[2 * k + 1] = v.y; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f0[k] = itw11<0>(tw, 4 * t + k);
+        f1[0] = itw11<1>(tw, 2 * t); f1[1] = itw11<1>(tw, 2 * t + 1);
+        f2 = itw11<2>(tw, t);
+        inv_pass8(x, f0, f1, f2, Q);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bufA[r * 257 + t] = x[r];          // e0
+    }
+    block_sync_lds();
+    {   // pass 1: p = (g << 6) | (r << 3) | l,  g = t >> 3, l = t & 7; e0 address of p: (p & 7) * 257 + (p >> 3)
+        const u32 g = t >> 3, l = t & 7u;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = bufA[l * 257 + ((g << 3) | (u32)r)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f0[k] = itw11<3>(tw, 4 * g + k);
+        f1[0] = itw11<4>(tw, 2 * g); f1[1] = itw11<4>(tw, 2 * g + 1);
+        f2 = itw11<5>(tw, g);
+        inv_pass8(x, f0, f1, f2, Q);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bufB[r * 264 + t] = x[r];          // e1 (t = (g << 3) | l)
+    }
+    block_sync_lds();
+    {   // pass 2: p = (h << 9) | (r << 6) | m,  h = t >> 6, m = t & 63; e1 address of p: p[5:3] * 264 + ((p >> 6) << 3 | p[2:0])
+        const u32 h = t >> 6, m = t & 63u;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = bufB[(m >> 3) * 264 + ((((h << 3) | (u32)r) << 3) | (m & 7u))];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f0[k] = itw11<6>(tw, 4 * h + k);
+        f1[0] = itw11<7>(tw, 2 * h); f1[1] = itw11<7>(tw, 2 * h + 1);
+        f2 = itw11<8>(tw, h);
+        inv_pass8(x, f0, f1, f2, Q);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bufA[r * 256 + t] = x[r];          // e2 (t = (h << 6) | m)
+    }
+    block_sync_lds();
+    {   // pass 3: p = (r << 8) | t; e2 address of p: p[8:6] * 256 + (p[10:9] << 6 | p[5:0]); stages on bits 9, 10
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = bufA[((((u32)r & 1u) << 2) | (t >> 6)) * 256 + ((((u32)r >> 1) << 6) | (t & 63u))];
+        const double2 g0 = itw11<9>(tw, 0), g1 = itw11<9>(tw, 1), g2 = itw11<10>(tw, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // bit 9 = register bit 1: pairs (r, r+2), r in {0,1,4,5}; stage index = r >> 2
+            const int r = (k >> 1) * 4 + (k & 1);
+            const double X = x[r], Y = x[r + 2];
+            x[r] = X + Y;
+            const double2 f = (k >> 1) ? g1 : g0;
+            x[r + 2] = modmul_q(Y - X, f.x, f.y, Q);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // bit 10 = register bit 2
+            const double X = x[r], Y = x[r + 4];
+            x[r] = X + Y;
+            x[r + 4] = modmul_q(Y - X, g2.x, g2.y, Q);
+        }
+    }
+}
+
+// SPLIT (N = 2048 only): 512-thread workgroup, inverse transforms on all 8 waves (split_inverse11), forward
+// transforms on waves 0..R-1, 4 MAC items per thread.
+template <int LOGN, int DG, bool AP, bool SPLIT = false, u32 NBUF_ = (AP ? 3 : 2), u32 NPRE_ = (AP ? 2 : 1)>
+__global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
                                                                u32 slot_stride, u64* __restrict__ acc_out) {
     using C = Cfg<LOGN>;
     constexpr int N = C::N, NP = C::NP, E = C::E;
-    constexpr u32 R = 2 * DG, T = 64 * R;
+    constexpr u32 R = 2 * DG, T = SPLIT ? 512 : 64 * R;
+    static_assert(!SPLIT || (LOGN == 11 && R <= 8 && R >= 4), "split inverse transform: N = 2048");
     extern __shared__ __align__(16) double smemd[];
     double* acc = smemd;          // [2][NP] evaluation form, |value| <= 0.6 Q
     double* dct = acc + 2 * NP;   // [R][NP]
@@ -722,7 +825,27 @@ __global__ __launch_bounds__(128 * DG) void k_blind_rotate64d(DevParams P, const
         };
         if constexpr (NPRE >= 1) request(std::integral_constant<u32, 0>{});
         if constexpr (NPRE >= 2) request(std::integral_constant<u32, 1>{});
-        if (wave < 2) {
+        if constexpr (SPLIT) {
+            const u32 c = wave >> 2, t = tid_v & 255u;
+            double x[8];
+            // exchange buffers live in dct rows 0..3 (dead until the digits are written)
+            split_inverse11(acc + c * NP, dct + c * NP, dct + (2 + c) * NP, tw, t, Q, x);
+            block_sync_lds();  // every thread has read its pass-3 inputs: the digit rows may be overwritten
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                double d = modmul_q(x[r], ninv.x, ninv.y, Q);
+                d = d > dhi ? d - Q : d;
+                d = d < dlo ? d + Q : d;
+                double u = d + doff;
+                const u32 pj = phys(((u32)r << 8) | t);
+#pragma unroll
+                for (u32 l = 0; l < (u32)DG; ++l) {
+                    const double fl = floor(u * invB);
+                    dct[(2 * l + c) * NP + pj] = fma(-fl, Bd, u) - halfB;  // digit in [-B/2, B/2)
+                    u = fl;
+                }
+            }
+        } else if (wave < 2) {
             double x[E];
             ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, tw, lane_v, Q, ninv, x);
 #pragma unroll
@@ -743,7 +866,7 @@ __global__ __launch_bounds__(128 * DG) void k_blind_rotate64d(DevParams P, const
         BCE_PROF_MARK(0);
         block_sync_lds();
         BCE_PROF_MARK(1);
-        ntt_forward_wave<LOGN>(dct + wave * NP, tw, lane_v, Q);
+        if (!SPLIT || wave < R) ntt_forward_wave<LOGN>(dct + wave * NP, tw, lane_v, Q);
         BCE_PROF_MARK(2);
         block_sync_lds();
         BCE_PROF_MARK(3);
@@ -803,7 +926,19 @@ __global__ __launch_bounds__(128 * DG) void k_blind_rotate64d(DevParams P, const
         block_sync_lds();
         BCE_PROF_MARK(5);
     }
-    if (wave < 2) {
+    if constexpr (SPLIT) {
+        const u32 c = wave >> 2, t = tid & 255u;
+        double x[8];
+        split_inverse11(acc + c * NP, dct + c * NP, dct + (2 + c) * NP, tw, t, Q, x);
+        u64* out = acc_out + ((size_t)blockIdx.x * 2 + c) * N;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const double y = modmul_q(x[r], ninv.x, ninv.y, Q);
+            const double v = y < 0.0 ? y + Q : y;
+            const double hi = floor(v * (1.0 / 4294967296.0));
+            out[((u32)r << 8) | t] = ((u64)(u32)hi << 32) | (u64)(u32)fma(-hi, 4294967296.0, v);
+        }
+    } else if (wave < 2) {
         double x[E];
         ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, tw, lane, Q, ninv, x);
         u64* out = acc_out + ((size_t)blockIdx.x * 2 + wave) * N;
@@ -847,12 +982,13 @@ hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32
                                  u64* acc_out, hipStream_t s) {
     using K = void (*)(DevParams, const bce_gate_desc*, u32, u32, u64*);
     const bool ap = P.method_ap != 0;
+    u32 threads = 128 * P.dG;
     K kern = nullptr;
     if (P.fp64 && P.dG == 3) {
         switch (P.logN) {
             case 9: kern = ap ? wd::k_blind_rotate64d<9, 3, true> : wd::k_blind_rotate64d<9, 3, false>; break;
             case 10: kern = ap ? wd::k_blind_rotate64d<10, 3, true> : wd::k_blind_rotate64d<10, 3, false>; break;
-            case 11: kern = ap ? wd::k_blind_rotate64d<11, 3, true> : wd::k_blind_rotate64d<11, 3, false>; break;
+            case 11: kern = ap ? wd::k_blind_rotate64d<11, 3, true, true> : wd::k_blind_rotate64d<11, 3, false, true>; threads = 512; break;
             default: break;
         }
     } else if (P.fp64 && P.dG == 4 && P.logN == 9) {
@@ -871,7 +1007,7 @@ hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32
     const size_t lds = blind_rotate64_lds_bytes(P);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_desc * instances), dim3(128 * P.dG), lds, s, P, d, n_desc, slot_stride, acc_out);
+    hipLaunchKernelGGL(kern, dim3(n_desc * instances), dim3(threads), lds, s, P, d, n_desc, slot_stride, acc_out);
     return hipGetLastError();
 }
 
