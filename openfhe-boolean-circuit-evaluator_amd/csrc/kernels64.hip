@@ -581,6 +581,20 @@ __device__ __forceinline__ void ntt_forward_wave(double* poly, const double2* tw
     store_pass<LOGN, 0>(poly, lane, x);
     wave_sync();
 }
+// forward NTT (N = 2048) whose stages on bits 10, 9, 8 were already applied by the producer: bits 7..3, then 2..0
+template <int LOGN>
+__device__ __forceinline__ void ntt_forward_wave_low8(double* poly, const double2* tw, u32 lane, double Q) {
+    static_assert(LOGN == 11, "laid out for N = 2048");
+    double x[Cfg<LOGN>::E];
+    load_pass<LOGN, 3>(poly, lane, x);
+    fwd_stages<LOGN, 3, 7, 3>(x, lane, tw, Q);
+    store_pass<LOGN, 3>(poly, lane, x);
+    wave_sync();
+    load_pass<LOGN, 0>(poly, lane, x);
+    fwd_stages<LOGN, 0, 2, 0>(x, lane, tw, Q);
+    store_pass<LOGN, 0>(poly, lane, x);
+    wave_sync();
+}
 // inverse NTT by one wave; |src| <= 0.6 Q bit-reversed; coefficient j = (r << 6) | lane in x[r], |x| <= 0.57 Q
 template <int LOGN>
 __device__ __forceinline__ void ntt_inverse_wave(const double* src, double* tmp, const double2* tw, u32 lane, double Q,
@@ -831,19 +845,46 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
             // exchange buffers live in dct rows 0..3 (dead until the digits are written)
             split_inverse11(acc + c * NP, dct + c * NP, dct + (2 + c) * NP, tw, t, Q, x);
             block_sync_lds();  // every thread has read its pass-3 inputs: the digit rows may be overwritten
+            // digits, then the first three FORWARD stages (bits 10, 9, 8 = this thread's register index) on each digit
+            // in registers: the forward transform below is left with bits 7..0 (two passes)
+            double u[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 double d = modmul_q(x[r], ninv.x, ninv.y, Q);
                 d = d > dhi ? d - Q : d;
                 d = d < dlo ? d + Q : d;
-                double u = d + doff;
-                const u32 pj = phys(((u32)r << 8) | t);
+                u[r] = d + doff;
+            }
+            const double2 w10 = tw[1], w9a = tw[2], w9b = tw[3];
 #pragma unroll
-                for (u32 l = 0; l < (u32)DG; ++l) {
-                    const double fl = floor(u * invB);
-                    dct[(2 * l + c) * NP + pj] = fma(-fl, Bd, u) - halfB;  // digit in [-B/2, B/2)
-                    u = fl;
+            for (u32 l = 0; l < (u32)DG; ++l) {
+                double v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const double fl = floor(u[r] * invB);
+                    v[r] = fma(-fl, Bd, u[r]) - halfB;  // digit in [-B/2, B/2)
+                    u[r] = fl;
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {  // bit 10: (r, r+4), twiddle tw[1]
+                    const double T = modmul_q(v[r + 4], w10.x, w10.y, Q);
+                    v[r + 4] = v[r] - T; v[r] = v[r] + T;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {  // bit 9: (r, r+2), r in {0,1,4,5}, twiddle tw[2 + (r >> 2)]
+                    const int r = (k >> 1) * 4 + (k & 1);
+                    const double2 w = (k >> 1) ? w9b : w9a;
+                    const double T = modmul_q(v[r + 2], w.x, w.y, Q);
+                    v[r + 2] = v[r] - T; v[r] = v[r] + T;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {  // bit 8: (2k, 2k+1), twiddle tw[4 + k]
+                    const double2 w = tw[4 + k];
+                    const double T = modmul_q(v[2 * k + 1], w.x, w.y, Q);
+                    v[2 * k + 1] = v[2 * k] - T; v[2 * k] = v[2 * k] + T;
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) dct[(2 * l + c) * NP + phys(((u32)r << 8) | t)] = v[r];
             }
         } else if (wave < 2) {
             double x[E];
@@ -866,7 +907,11 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
         BCE_PROF_MARK(0);
         block_sync_lds();
         BCE_PROF_MARK(1);
-        if (!SPLIT || wave < R) ntt_forward_wave<LOGN>(dct + wave * NP, tw, lane_v, Q);
+        if constexpr (SPLIT) {
+            if (wave < R) ntt_forward_wave_low8<LOGN>(dct + wave * NP, tw, lane_v, Q);
+        } else {
+            ntt_forward_wave<LOGN>(dct + wave * NP, tw, lane_v, Q);
+        }
         BCE_PROF_MARK(2);
         block_sync_lds();
         BCE_PROF_MARK(3);
