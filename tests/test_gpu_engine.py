@@ -138,6 +138,21 @@ def test_std128_every_blind_rotation_kernel_bit_exact(std128, bce, variant, monk
         assert o.decrypt(out[i]) == _truth(g, a, b)
 
 
+def test_launch_size_does_not_change_ciphertexts(toy, std128, bce):
+    """Launch size selects the blind-rotation kernel (<= #CUs workgroups: one per CU) and how many workgroups share
+    one bootstrap's key-switch rows (S = 16 ... 1): the same gate must give the same ciphertext alone and inside a
+    large launch."""
+    for (o, c), big in ((toy, 1500), (std128, 700)):
+        ca, cb = o.encrypt(1, 7000), o.encrypt(1, 7001)
+        want = o.eval_bingate(bce.NAND, ca, cb)
+        c.pool_reserve(2 + big)
+        c.lwe_write([0, 1], np.stack([ca, cb]))
+        for nb in (1, 3, 40, 300, big):
+            c.EvalGates(bce.make_descs([(bce.NAND, 0, 1, 2 + i) for i in range(nb)]))
+            out = c.lwe_read(np.arange(2, 2 + nb, dtype=np.uint32))
+            assert all(np.array_equal(out[i], want) for i in range(nb)), "launch of %d differs" % nb
+
+
 def test_folded_not_refresh_and_unary(toy, bce):
     """neg0/neg1 folding == explicit EvalNOT; REFRESH == Bootstrap(); NOT/COPY ops."""
     o, c = toy
