@@ -108,12 +108,21 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # test-only knobs (a one-GPU box rehearsing the N > 1 path): all ranks on device 0, gloo instead of RCCL
+    if os.environ.get("BCE_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("BCE_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = "cuda" if backend == "nccl" else "cpu"  # where the few scalars of the result are reduced
 
     # ---- setup (untimed): context, keys (same seed on every rank = replicated), circuit, inputs
     t_setup = time.time()
@@ -124,18 +133,23 @@ def main():
     circ.ReadBristol(path, new_flag=args.circuit.startswith("sha256_new"))
     if args.xor_fast:
         circ.setXorFast(True)
+    shard_mode = 0 if args.shard == "instances" else 1
+    if args.relevel and world > 1 and shard_mode == 1:
+        args.relevel = False  # the bootstrap-depth schedule is not defined for gate sharding: reference gate levels
     if args.relevel:
         circ.setRelevel(True)
     info = circ.info()
-    shard_mode = 0 if args.shard == "instances" else 1
-    K_total = args.instances * world if shard_mode == 0 else args.instances
+    # instances (default, weak scaling): every rank evaluates ITS OWN K input blocks with its own circuit object --
+    # independent units, no data-path collective at all (only the barrier / reductions of this script).
+    # gates: one set of K blocks, every level's gates split over the ranks, boundary ciphertexts exchanged (RCCL).
+    K_total = args.instances
     circ.setInstances(K_total)
     xch = None
-    if world > 1:
+    if world > 1 and shard_mode == 1:
         from importlib import import_module
         xch = import_module("openfhe-boolean-circuit-evaluator_amd.dist").Exchange(
             circ, shard_mode, encrypted=True, device=torch.device("cuda", local_rank))
-    rng = np.random.default_rng(12345)
+    rng = np.random.default_rng(12345 + (rank if shard_mode == 0 else 0))
     widths = info["n_input_bits"]
     inputs = []
     for k in range(K_total):
@@ -179,18 +193,19 @@ def main():
     elapsed = time.time() - t0
     tm = cc.timing()
     my_boot = tm["bootstraps"]
+    # correctness of the timed work: decrypted outputs of every instance == plaintext evaluation
+    got = [circ.Outputs(k)[0] for k in range(K_total)]
+    verified = got == expect
     if dist is not None:
-        t = torch.tensor([elapsed, float(my_boot)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(my_boot), 0.0 if verified else 1.0], dtype=torch.float64, device=red_dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
         total_boot = float(t[1])
+        verified = float(tmax[2]) == 0.0      # every rank's outputs
     else:
         total_boot = float(my_boot)
-    # correctness of the timed work: decrypted outputs of every instance == plaintext evaluation
-    got = [circ.Outputs(k)[0] for k in range(K_total)]
-    verified = got == expect
     st = circ.stats()
 
     traffic = None
