@@ -234,3 +234,62 @@ def test_new_format_arithmetic_circuits(bce):
         got, info = run("mult2_64.txt", a, b)          # two 64-bit outputs: high half first, then low half
         assert info["n_output_bits"] == 128 and got == ((a * b) >> 64) | (((a * b) & M) << 64)
     assert run("zero_equal.txt", 0)[0] == 1 and run("zero_equal.txt", 5)[0] == 0
+
+
+def test_new_format_floating_point_circuits(bce):
+    """examples/new_bristol_ckts/fp of the reference: IEEE-754 binary64 add / mul / eq / double -> int64, wires
+    LSB first, round to nearest even.  Pinned against the host's own double arithmetic on seeded operands."""
+    import struct
+
+    import numpy as np
+
+    def d2u(x):
+        return struct.unpack("<Q", struct.pack("<d", x))[0]
+
+    def u2d(u):
+        return struct.unpack("<d", struct.pack("<Q", u))[0]
+
+    circs = {}
+
+    def run(name, *vals):
+        if name not in circs:
+            c = bce.Circuit(None)
+            c.ReadBristol(os.path.join(CIRCUITS, name), new_flag=True)
+            circs[name] = c
+        c = circs[name]
+        c.Reset()
+        c.setPlaintext(True)
+        c.SetInput([_bits(v, 64) for v in vals])
+        c.Clock()
+        return sum(b << i for i, b in enumerate(c.Outputs(0)[0]))
+
+    rng = np.random.default_rng(754)
+    ops = [(1.5, 2.25), (0.1, 0.2), (1e10, -3.5), (1e308, 1e308), (-7.0, 7.0), (3.0, 3.0)]
+    for _ in range(10):  # normal numbers over a wide exponent range
+        m = rng.uniform(1.0, 2.0, 2) * np.array([1.0, -1.0])[rng.integers(0, 2, 2)]
+        ops.append((float(m[0] * 2.0 ** int(rng.integers(-300, 300))), float(m[1] * 2.0 ** int(rng.integers(-300, 300)))))
+    for a, b in ops:
+        assert run("FP-add.txt", d2u(a), d2u(b)) == d2u(a + b), (a, b)
+        assert run("FP-mul.txt", d2u(a), d2u(b)) == d2u(a * b), (a, b)
+        assert run("FP-eq.txt", d2u(a), d2u(b)) == (1 if a == b else 0)
+    for a in (3.7, -3.7, 2.5, 3.5, -2.5, 0.49, -0.49, 123456789.5, 1e15 + 0.5, float(2 ** 52) + 1.0):
+        want = int(np.rint(a)) & ((1 << 64) - 1)      # rint = round half to even
+        assert run("FP-f2i.txt", d2u(a)) == want, a
+
+
+def test_new_format_aes128(bce):
+    """examples/new_bristol_ckts/crypto/aes_128.txt: inputs (key, plaintext), each the 128-bit big-endian integer of
+    its bytes on wires LSB first; same for the ciphertext.  Vectors: FIPS-197 App. B / C.1 and the all-zero block."""
+    c = bce.Circuit(None)
+    c.ReadBristol(os.path.join(CIRCUITS, "aes_128_new.txt"), new_flag=True)
+    assert c.info()["n_input_bits"] == [128, 128] and c.info()["n_output_bits"] == 128
+    vectors = [("000102030405060708090a0b0c0d0e0f", "00112233445566778899aabbccddeeff", "69c4e0d86a7b0430d8cdb78070b4c55a"),
+               ("2b7e151628aed2a6abf7158809cf4f3c", "3243f6a8885a308d313198a2e0370734", "3925841d02dc09fbdc118597196a0b32"),
+               ("00000000000000000000000000000000", "00000000000000000000000000000000", "66e94bd4ef8a2c3b884cfa59ca342b2e")]
+    for key, pt, ct in vectors:
+        c.Reset()
+        c.setPlaintext(True)
+        c.SetInput([_bits(int(key, 16), 128), _bits(int(pt, 16), 128)])
+        c.Clock()
+        assert sum(b << i for i, b in enumerate(c.Outputs(0)[0])) == int(ct, 16)
+
