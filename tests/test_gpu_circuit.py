@@ -175,6 +175,32 @@ def test_sha256_new_format_std128_four_vectors_in_lock_step(bce, std_cc):
     print("sha256 x%d: %.1f s, %.0f bootstraps/s" % (len(vecs), st["total_ms"] / 1e3, st["bootstraps"] / st["total_ms"] * 1e3))
 
 
+def test_new_format_aes128_and_fp_eq_encrypted_std128(bce, std_cc):
+    """Two more circuits of the reference's Bristol-Fashion corpus end to end under encryption: aes_128 (two 128-bit
+    input buses, FIPS-197 C.1 vector, bootstrap-depth schedule) and the IEEE-754 equality test."""
+    import struct
+    c = bce.Circuit(std_cc)
+    c.ReadBristol(os.path.join(CIRCUITS, "aes_128_new.txt"), new_flag=True)
+    key, pt, ct = "000102030405060708090a0b0c0d0e0f", "00112233445566778899aabbccddeeff", "69c4e0d86a7b0430d8cdb78070b4c55a"
+    bits = lambda v, n: [(v >> i) & 1 for i in range(n)]
+    c.Reset()
+    c.setEncrypted(True)
+    c.setRelevel(True)
+    c.SetInput([bits(int(key, 16), 128), bits(int(pt, 16), 128)])
+    c.Clock()
+    assert sum(b << i for i, b in enumerate(c.Outputs(0)[0])) == int(ct, 16)
+    e = bce.Circuit(std_cc)
+    e.ReadBristol(os.path.join(CIRCUITS, "FP-eq.txt"), new_flag=True)
+    d2u = lambda x: struct.unpack("<Q", struct.pack("<d", x))[0]
+    e.setInstances(2)
+    e.Reset()
+    e.setEncrypted(True)
+    e.SetInput([bits(d2u(2.5), 64), bits(d2u(2.5), 64)], instance=0)
+    e.SetInput([bits(d2u(2.5), 64), bits(d2u(-2.5), 64)], instance=1)
+    e.Clock()
+    assert e.Outputs(0)[0][0] == 1 and e.Outputs(1)[0][0] == 0
+
+
 @pytest.mark.parametrize("batched", [True, False])
 def test_verify_mode_repairs_an_injected_fault(bce, toy_cc, batched):
     """Fault injection for the reference's verify-and-fix path (src/gate.cpp:153-160): the ciphertext of
