@@ -924,7 +924,9 @@ __device__ __forceinline__ void split_inverse_rest(const SplitInv<REGTW>& S, con
     else inv_pass4_last(x, twf[tw_pos<2>(1)], twf[tw_pos<2>(0)], ninv, wlast, Q);
 }
 
-template <int DG, int WPS>  // WPS = waves per SIMD the register budget allows: 2 (one workgroup per CU) or 4 (two)
+// AP = true: AP/DM accumulator -- one step per non-zero base-baseR digit of -a_i, a single RGSW key selected by the
+// digit, the product REPLACES the accumulator (no monomials); everything else is shared with GINX.
+template <int DG, int WPS, bool AP = false>  // WPS = waves per SIMD the register budget allows: 2 (one workgroup per CU) or 4 (two)
 __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
                                                                    u32 slot_stride, u32* __restrict__ acc_out) {
     static_assert(DG == 4, "the split inverse transform is laid out for 8 waves");
@@ -957,7 +959,9 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
 
     const uint2 ninv = make_uint2(P.Ninv, P.Ninv_s), wlast = make_uint2(P.Winv_last, P.Winv_last_s);
     constexpr u32 rgsw = R * 2 * N;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(P.bsk), 0, (int)(n * 2 * rgsw * 4), 0x00020000);
+    // GINX key: n * 2 RGSW ciphertexts; AP key: n * baseR * dR of them (< 2^31 bytes for every 32-bit parameter set)
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(P.bsk), 0, AP ? 0x7FFFFFFF : (int)(n * 2 * rgsw * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t psi_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(P.psi_tab), 0, N * 4, 0x00020000);
     // digit extraction constants (see the throughput kernel)
     const u32 gb = P.gBits, Qh = Q >> 1;
@@ -977,10 +981,21 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
     block_sync_lds();
 
     BCE_PROF_INIT();
-    for (u32 step = 0; step < n; ++step) {
-        const u32 ap = ((q - av[step]) & qm) * P.factor;
-        if (ap == 0) continue;  // acc unchanged: xa still holds its pass 0
-        const u32 rowb = step * (2 * rgsw * 4);
+    const u32 nsteps = AP ? n * P.dR : n;
+    for (u32 step = 0; step < nsteps; ++step) {
+        u32 ap = 0, rowb;
+        if constexpr (!AP) {
+            ap = ((q - av[step]) & qm) * P.factor;
+            if (ap == 0) continue;  // acc unchanged: xa still holds its pass 0
+            rowb = step * (2 * rgsw * 4);
+        } else {
+            const u32 i = step / P.dR, kd = step - i * P.dR;
+            u32 aI = (q - av[i]) & qm;
+            for (u32 t = 0; t < kd; ++t) aI /= P.baseR;
+            const u32 a0 = aI % P.baseR;
+            if (a0 == 0) continue;      // rgsw-acc-dm.cpp EvalAcc: digit 0 is skipped
+            rowb = (((i * P.baseR + a0) * P.dR + kd) * rgsw) * 4u;
+        }
         // key rows of this step, requested during phase 1 (a quarter at the start of each inverse pass),
         // consumed in phase 3: all 16 with the 256-register budget, the first half of each key with the
         // 128-register one (the rest is requested at the end of phase 2)
@@ -991,7 +1006,7 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
 #pragma unroll
             for (u32 l = k * G; l < (k + 1) * G; ++l) {
                 kA[l] = bsk_row(rsrc, tid * 16u, rowb + l * (2 * N * 4));
-                kB[l] = bsk_row(rsrc, tid * 16u, rowb + (rgsw + l * 2 * N) * 4);
+                if constexpr (!AP) kB[l] = bsk_row(rsrc, tid * 16u, rowb + (rgsw + l * 2 * N) * 4);
             }
         };
         // (1) inverse transforms on all 8 waves (passes 1..4), SignedDigitDecompose in closed form, and the
@@ -1026,7 +1041,7 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
 #pragma unroll
             for (u32 l = PR; l < R; ++l) kA[l] = bsk_row(rsrc, tid * 16u, rowb + l * (2 * N * 4));
 #pragma unroll
-            for (u32 l = PR; l < R; ++l) kB[l] = bsk_row(rsrc, tid * 16u, rowb + (rgsw + l * 2 * N) * 4);
+            for (u32 l = PR; l < R; ++l) if constexpr (!AP) kB[l] = bsk_row(rsrc, tid * 16u, rowb + (rgsw + l * 2 * N) * 4);
         }
         block_sync_lds();
         BCE_PROF_MARK(3);
@@ -1037,13 +1052,22 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
             for (u32 l = 0; l < R; ++l) {
                 const uint4 d = *reinterpret_cast<const uint4*>(dct + l * NP + mpp);
                 sp[0] += (u64)d.x * kA[l].x; sp[1] += (u64)d.y * kA[l].y; sp[2] += (u64)d.z * kA[l].z; sp[3] += (u64)d.w * kA[l].w;
-                sn[0] += (u64)d.x * kB[l].x; sn[1] += (u64)d.y * kB[l].y; sn[2] += (u64)d.z * kB[l].z; sn[3] += (u64)d.w * kB[l].w;
+                if constexpr (!AP) {
+                    sn[0] += (u64)d.x * kB[l].x; sn[1] += (u64)d.y * kB[l].y; sn[2] += (u64)d.z * kB[l].z; sn[3] += (u64)d.w * kB[l].w;
+                }
             }
-            const u32 a4 = ap & 3u;
-            const uint2 Ia = make_uint2(P.I4[a4], P.I4s[a4]);
-            const uint2 Ina = make_uint2(P.I4[(4u - a4) & 3u], P.I4s[(4u - a4) & 3u]);
             u32 anew[4];
-            ginx_mac_tail<LOGN, true>(P, psi_rsrc, Q, ap, Ia, Ina, mp0, acc + mc * NP + mpp, sp, sn, anew);
+            if constexpr (AP) {
+                // acc[c] = sum_l dct[l] * ek[l][c]   (rgsw-acc-dm.cpp AddToAcc: the product REPLACES acc)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) anew[e] = barrett_fold(sp[e], P.c32, Q, P.red_shift, P.red_mu);
+                *reinterpret_cast<uint4*>(acc + mc * NP + mpp) = make_uint4(anew[0], anew[1], anew[2], anew[3]);
+            } else {
+                const u32 a4 = ap & 3u;
+                const uint2 Ia = make_uint2(P.I4[a4], P.I4s[a4]);
+                const uint2 Ina = make_uint2(P.I4[(4u - a4) & 3u], P.I4s[(4u - a4) & 3u]);
+                ginx_mac_tail<LOGN, true>(P, psi_rsrc, Q, ap, Ia, Ina, mp0, acc + mc * NP + mpp, sp, sn, anew);
+            }
             split_pass0(S, twf, anew, xa, Q, P.mu32);  // mc == c, mp0 == 4 t: this thread's pass-0 registers
         }
         BCE_PROF_MARK(4);
@@ -1097,14 +1121,15 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n
     const int occ = P.occupancy_target;
     const bool ap = P.method_ap != 0;
     BrKernel kern = nullptr;
-    if (P.variant != 1 && P.logN == 10 && P.dG == 4 && P.lazy && !ap) {
+    if (P.variant != 1 && P.logN == 10 && P.dG == 4 && P.lazy) {
         // N = 1024, dG = 4 (STD128 class): the split-transform kernel, with the 256-register budget while the
         // launch leaves every workgroup a CU of its own, else with the 128-register one (two per CU);
         // measured against the one-wave-per-transform kernel over launch sizes 64..6144: tools/kernel_sweep.py
         const size_t lds_lat = blind_rotate_lat_lds_bytes(P);
         const bool alone = (P.variant == 2) || (P.variant == 0 && grid.x <= P.cu_count);
         const bool x1 = alone && P.variant != 3;
-        kern = x1 ? k_blind_rotate_lat<4, 2> : k_blind_rotate_lat<4, 4>;
+        if (ap) kern = x1 ? k_blind_rotate_lat<4, 2, true> : k_blind_rotate_lat<4, 4, true>;
+        else kern = x1 ? k_blind_rotate_lat<4, 2, false> : k_blind_rotate_lat<4, 4, false>;
         if (kernel_id) *kernel_id = x1 ? BCE_BR_SPLIT_X1 : BCE_BR_SPLIT_X2;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lat);
         if (e != hipSuccess) return e;

@@ -284,6 +284,35 @@ def test_ap_std128_gate_same_seed_keys(bce, orc):
     assert list(c.Decrypt([2, 3])) == [0, 1]
 
 
+@pytest.fixture(scope="module")
+def std128opt_ap_oracle(orc):
+    o = orc.Oracle(orc.STD128_OPT, orc.AP)
+    o.keygen(4242)
+    yield o
+    o.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 3])
+def test_std128_opt_ap_every_kernel_same_seed_keys(bce, std128opt_ap_oracle, variant, monkeypatch):
+    """`-s STD128_OPT -m AP` of the reference's command line (src/utils.cpp:167-185): N = 1024 with 4 gadget digits, so
+    the AP method also runs on the split-transform kernel (automatic choice: one workgroup per CU for this small
+    launch; 3: two per CU) besides the one-wave-per-transform kernel (1).  2.1 GB key from the same seed on both sides."""
+    o = std128opt_ap_oracle
+    monkeypatch.setenv("BCE_VARIANT", str(variant))
+    c = bce.BinFHEContext(bce.STD128_OPT, bce.AP)
+    c.KeyGen(4242)
+    ca, cb = o.encrypt(1, 10), o.encrypt(0, 11)
+    c.pool_reserve(5)
+    c.lwe_write([0, 1], np.stack([ca, cb]))
+    c.EvalGates([(bce.NAND, 0, 1, 2), (bce.OR, 0, 1, 3), (bce.XOR_FAST, 0, 1, 4)])
+    out = c.lwe_read([2, 3, 4])
+    assert np.array_equal(out[0], o.eval_bingate(bce.NAND, ca, cb))
+    assert np.array_equal(out[1], o.eval_bingate(bce.OR, ca, cb))
+    assert np.array_equal(out[2], o.eval_bingate(bce.XOR_FAST, ca, cb))
+    assert list(c.Decrypt([2, 3, 4])) == [1, 1, 1]
+    c.close()
+
+
 # ---- 64-bit ring modulus (STD192: Q ~ 2^37, N = 2048): kernels64.hip -------------------------------
 def _custom64(orc, base_g_bits=13):
     L = orc.lib()
