@@ -1,4 +1,4 @@
-// kernels.hip -- hand-written gfx950 (CDNA4) kernels of the gate-bootstrapping engine.
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels of the gate-bootstrapping engine (32-bit ring modulus).
 //
 // Hot path replaced: OpenFHE's BinFHEContext::EvalBinGate as called by the reference at
 // src/gate.cpp:133,146,172,200-202 (one call per gate inside an OpenMP task,
@@ -6,18 +6,24 @@
 //
 //   k_blind_rotate        LWE prep (ct1+ct2, folded NOTs) -> test vector -> n x AddToAcc
 //                         (2 INTT, signed digit decomposition, 2*dG NTT, RGSW MAC with the
-//                         bootstrapping key streamed from HBM/L2, monomial multiply) -> INTT
-//   k_tail                transpose + sample extract + ModSwitch(Q->qKS) + LWE KeySwitch
-//                         (row gather) + ModSwitch(qKS->q)
+//                         bootstrapping key streamed from HBM/L2, monomial multiply) -> INTT;
+//                         ONE WAVE PER TRANSFORM: every 32-bit parameter set, GINX and AP
+//   k_blind_rotate_lat    the same computation for N = 1024, dG = 4 (STD128 / STD128_OPT) with the inverse
+//                         transforms SPLIT over all 8 waves, passes fused across phases and key rows
+//                         requested ahead of their use; 256- and 128-register builds (one / two
+//                         workgroups per CU), chosen by launch size in launch_blind_rotate()
+//   k_tail_gather/_finish transpose + sample extract + ModSwitch(Q->qKS) + LWE KeySwitch (row gather,
+//                         16-byte pieces per lane, rows split over waves / workgroups) + ModSwitch(qKS->q)
 //
-// All arithmetic is 32-bit unsigned modular integer (Q < 2^28): Shoup/Harvey lazy
-// butterflies with values in [0,4Q) (forward) / [0,2Q) (inverse), 64-bit MAC sums reduced
-// by one Barrett step.  No MFMA: nothing here is a dense contraction.
+// All arithmetic is 32-bit unsigned modular integer (Q < 2^28): lazy Shoup butterflies on register
+// pairs (forward, values below 22Q, 5 instructions) and compile-time bound-tracked Gentleman-Sande
+// stages (inverse), 64-bit MAC sums folded and reduced by lazy Barrett steps; the non-lazy Harvey
+// forms remain for Q >= 2^27.6.  No MFMA: nothing here is a dense contraction.
 //
-// NTT organisation (64-wide wavefronts): ONE WAVE PER POLYNOMIAL, E = N/64 coefficients per
-// lane held in registers; log2(E) radix-2 stages run in registers per pass, with 2 (or 3)
-// LDS re-shuffles per transform instead of one barrier per stage.  A polynomial is stored
-// in LDS with 4 pad words per 64 so that all three access patterns are bank-conflict free.
+// NTT organisation (64-wide wavefronts): E = N/64 coefficients per lane held in registers, log2(E)
+// radix-2 stages per register pass, LDS re-shuffles between passes instead of one barrier per stage.
+// A polynomial is stored in LDS with 4 pad words per 64 (see DESIGN.md section 4 for the measured
+// access-shape costs and for what is and is not on the critical path).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
