@@ -627,7 +627,7 @@ int bce_keygen(bce_ctx* c, const uint8_t seed[32]) {
     if (rc) return rc;
     std::memcpy(c->seed, seed, 32);
     const u32 n = c->n, N = c->N;
-    const u64 Q = c->Q, qKS = c->qKS;
+    const u64 qKS = c->qKS;
     const GaussSampler gauss(3.19);
     c->s.resize(n);
     c->z.resize(N);
