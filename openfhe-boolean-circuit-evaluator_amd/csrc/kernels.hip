@@ -988,6 +988,7 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
 
     BCE_PROF_INIT();
     const u32 nsteps = AP ? n * P.dR : n;
+    if constexpr (WPS >= 4) __builtin_amdgcn_s_setprio(2);
     for (u32 step = 0; step < nsteps; ++step) {
         u32 ap = 0, rowb;
         if constexpr (!AP) {
@@ -1039,7 +1040,13 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
         block_sync_lds();
         BCE_PROF_MARK(1);
         // (2) one wave per decomposed polynomial: the remaining 8 forward stages, in place
+        // two workgroups per CU: the multiplier-bound forward transforms run at LOW wave priority, so the other
+        // workgroup's latency-bound phases (inverse passes, MAC tail) get their issue slots first and the transform
+        // waves fill the gaps (+1..4 %, same-box A/B; the opposite policy costs 7 %, and a lone workgroup loses 6 %
+        // with either, hence only in this build)
+        if constexpr (WPS >= 4) __builtin_amdgcn_s_setprio(0);
         ntt_forward_wave_low8(dct + wave * NP, twf, lane, Q);
+        if constexpr (WPS >= 4) __builtin_amdgcn_s_setprio(2);
         BCE_PROF_MARK(2);
         if constexpr (PR < R) {
             // 128-register build: the transform's registers are free again -- request the second half of the
