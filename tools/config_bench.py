@@ -21,6 +21,7 @@ CONFIGS = [
     ("3 AES-expanded STD128_OPT GINX", "AES-expanded.txt", "old", "STD128_OPT", "GINX", [1, 16]),
     ("3r AES-expanded STD128_OPT GINX bootstrap-depth schedule", "AES-expanded.txt", "old", "STD128_OPT", "GINX", [1, 32]),
     ("4 sha256 (new format) STD128_OPT GINX", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
+    ("4r sha256 (new format) STD128_OPT GINX bootstrap-depth schedule", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
     ("5 adder_64bit STD192 AP", "adder_64bit.txt", "old", "STD192", "AP", [64]),
     ("5b AES-expanded STD192 AP", "AES-expanded.txt", "old", "STD192", "AP", [2]),
 ]
