@@ -314,21 +314,21 @@ def test_std128_opt_ap_every_kernel_same_seed_keys(bce, std128opt_ap_oracle, var
 
 
 # ---- 64-bit ring modulus (STD192: Q ~ 2^37, N = 2048): kernels64.hip -------------------------------
-def _custom64(orc, base_g_bits=13):
+def _custom64(orc, base_g_bits=13, N=512):
     L = orc.lib()
-    Q = L.bo_previous_prime(L.bo_first_prime(37, 1024), 1024)      # 37-bit prime = 1 mod 2N, N = 512
-    #       n   N    q    Q  qKS      baseKS baseG             baseR
-    return (16, 512, 512, Q, 1 << 15, 32,    1 << base_g_bits, 23)   # base 2^13: 3 gadget digits, 2^10: 4
+    Q = L.bo_previous_prime(L.bo_first_prime(37, 2 * N), 2 * N)    # 37-bit prime = 1 mod 2N
+    #       n   N  q    Q  qKS      baseKS baseG             baseR
+    return (16, N, 512, Q, 1 << 15, 32,    1 << base_g_bits, 23)   # base 2^13: 3 gadget digits, 2^10: 4
 
 
-@pytest.mark.parametrize("dg", [3, 4])
+@pytest.mark.parametrize("dg,N", [(3, 512), (4, 512), (3, 1024)])
 @pytest.mark.parametrize("arith", ["fp64", "int64"])
 @pytest.mark.parametrize("method", ["GINX", "AP"])
-def test_q64_custom_context_bit_exact_stages(bce, orc, method, arith, dg, monkeypatch):
+def test_q64_custom_context_bit_exact_stages(bce, orc, method, arith, dg, N, monkeypatch):
     """The 64-bit-modulus path has two blind-rotation kernels: exact-integer doubles (default for Q < 2^39) and
     64-bit integer Shoup arithmetic (BCE_FP64=0); both must match the oracle bit for bit at every stage."""
     monkeypatch.setenv("BCE_FP64", "1" if arith == "fp64" else "0")
-    params = _custom64(orc, 13 if dg == 3 else 10)
+    params = _custom64(orc, 13 if dg == 3 else 10, N)
     o = orc.Oracle(method=getattr(orc, method), custom=params)
     o.keygen(31337)
     c = bce.BinFHEContext(method=getattr(bce, method), custom=params)
