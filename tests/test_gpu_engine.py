@@ -284,6 +284,32 @@ def test_ap_std128_gate_same_seed_keys(bce, orc):
     assert list(c.Decrypt([2, 3])) == [0, 1]
 
 
+@pytest.mark.parametrize("method", ["GINX", "AP"])
+def test_medium_28bit_modulus_non_lazy_path_bit_exact_stages(bce, orc, method):
+    """MEDIUM (n = 422, N = 1024, 28-bit Q, base 2^10: 3 gadget digits): 22 Q does not fit 32 bits, so the kernels take
+    the non-lazy Harvey forms (values in [0, 4Q), canonical digits, exact Barrett) -- a code path no other parameter
+    set of the tests reaches.  Keys from the same seed on both sides."""
+    o = orc.Oracle(orc.MEDIUM, getattr(orc, method))
+    o.keygen(606)
+    c = bce.BinFHEContext(bce.MEDIUM, getattr(bce, method))
+    c.KeyGen(606)
+    assert o.params == c.params and o.params["Q"] >= (1 << 27) and o.params["dG"] == 3
+    cases = [x for x in _gate_cases(o, base=500) if x[0] in (bce.AND, bce.NOR, bce.XOR_FAST)][2:6]
+    nb = len(cases)
+    c.pool_reserve(3 * nb)
+    c.lwe_write(np.arange(2 * nb, dtype=np.uint32), np.concatenate([np.stack([ca, cb]) for (_, _, _, ca, cb) in cases]))
+    descs = [(g, 2 * i, 2 * i + 1, 2 * nb + i) for i, (g, _, _, _, _) in enumerate(cases)]
+    acc, lweN, ks = c.debug_eval_stages(descs)
+    out = c.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32))
+    for i, (g, a, b, ca, cb) in enumerate(cases):
+        r_acc = o.blind_rotate(g, o.gate_prep(g, ca, cb))
+        assert np.array_equal(acc[i], r_acc), "accumulator differs, case %d" % i
+        assert np.array_equal(out[i], o.eval_bingate(g, ca, cb))
+        assert o.decrypt(out[i]) == _truth(g, a, b)
+    o.close()
+    c.close()
+
+
 @pytest.fixture(scope="module")
 def std128opt_ap_oracle(orc):
     o = orc.Oracle(orc.STD128_OPT, orc.AP)
