@@ -177,6 +177,27 @@ def test_folded_not_refresh_and_unary(toy, bce):
     assert o.decrypt(x) == 1
 
 
+def test_edge_cases_of_the_frontier_call(toy, bce):
+    """Empty frontier; the same ciphertext on both inputs (OpenFHE throws for the same OBJECT and the reference retries
+    with a fresh encryption, src/gate.cpp:129-152 -- here handles are values, so it is simply evaluated); output
+    written over an input of the same gate; unknown op."""
+    o, c = toy
+    ca = o.encrypt(1, 8000)
+    c.pool_reserve(8)
+    c.lwe_write([0], ca[None, :])
+    c.EvalGates(bce.make_descs([]))                                 # nothing to do, no error
+    c.EvalGates([(bce.AND, 0, 0, 1), (bce.NAND, 0, 0, 2)])          # in0 == in1
+    out = c.lwe_read([1, 2])
+    assert np.array_equal(out[0], o.eval_bingate(bce.AND, ca, ca)) and o.decrypt(out[0]) == 1
+    assert np.array_equal(out[1], o.eval_bingate(bce.NAND, ca, ca)) and o.decrypt(out[1]) == 0
+    c.lwe_write([3], out[1][None, :])
+    c.EvalGates([(bce.OR, 0, 3, 3)])                                # out == in1: read in the prologue, written by the tail
+    assert np.array_equal(c.lwe_read([3])[0], o.eval_bingate(bce.OR, ca, out[1]))
+    with pytest.raises(bce.BceError) as e:
+        c.EvalGates([(9, 0, 0, 4)])
+    assert e.value.code == bce.ERR_ARG
+
+
 def orc_and(bce):
     return bce.AND  # same numeric value in the oracle (BINGATE order)
 
