@@ -595,6 +595,75 @@ __device__ __forceinline__ void ntt_forward_wave_low8(double* poly, const double
     store_pass<LOGN, 0>(poly, lane, x);
     wave_sync();
 }
+// Forward phase of the 8-wave (N = 2048) workgroup: 6 polynomials whose stages on bits 10, 9, 8 are done.  One
+// transform per wave would put two full transforms on two of the four SIMDs (waves w and w + 4 share a SIMD), so
+// waves 0..3 take polynomials 0..3 (32 coefficients per lane: bits 7..3, then 2..0) and waves 4..7 take HALF of
+// polynomial 4 or 5 each (wave 4 + 6: polynomial 4, wave 5 + 7: polynomial 5; 16 coefficients per lane: bits 7..4,
+// then 3..0): every SIMD carries 1.5 transforms.  The two passes are separated by ONE workgroup barrier (the half
+// transforms exchange data across two waves), which every wave executes.
+template <int LOGN>
+__device__ __forceinline__ void forward_phase_balanced(double* dct, int NP, const double2* __restrict__ tw, u32 wave, u32 lane,
+                                                       double Q) {
+    static_assert(LOGN == 11, "laid out for N = 2048, 6 polynomials on 8 waves");
+    if (wave < 4) {
+        double* poly = dct + wave * NP;
+        double x[Cfg<LOGN>::E];
+        load_pass<LOGN, 3>(poly, lane, x);
+        fwd_stages<LOGN, 3, 7, 3>(x, lane, tw, Q);
+        store_pass<LOGN, 3>(poly, lane, x);
+        block_sync_lds();
+        load_pass<LOGN, 0>(poly, lane, x);
+        fwd_stages<LOGN, 0, 2, 0>(x, lane, tw, Q);
+        store_pass<LOGN, 0>(poly, lane, x);
+    } else {
+        double* poly = dct + (4 + (wave & 1u)) * NP;
+        const u32 v = ((wave >> 1) & 1u) * 64u + lane;  // 128 virtual lanes per polynomial
+        double x[16];
+        {   // pass A: registers = position bits 7..4; v[3:0] = p[3:0], v[6:4] = p[10:8]
+            const u32 hi = v >> 4, base = (hi << 8) | (v & 15u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = poly[phys(base | ((u32)r << 4))];
+#pragma unroll
+            for (int B = 7; B >= 4; --B) {           // stage on bit B = register bit B - 4; twiddle tw[m + (p >> (B+1))]
+                const int rb = B - 4;
+                const u32 m = 1u << (10 - B);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (r & (1 << rb)) continue;
+                    const double2 w = tw[m + ((hi << (7 - B)) | (u32)(r >> (rb + 1)))];
+                    const double X = x[r];
+                    const double T = modmul_q(x[r | (1 << rb)], w.x, w.y, Q);
+                    x[r] = X + T;
+                    x[r | (1 << rb)] = X - T;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) poly[phys(base | ((u32)r << 4))] = x[r];
+        }
+        block_sync_lds();
+        {   // pass B: registers = position bits 3..0; v = p[10:4]
+            const u32 base = v << 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = poly[phys(base | (u32)r)];
+#pragma unroll
+            for (int B = 3; B >= 0; --B) {
+                const u32 m = 1u << (10 - B);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (r & (1 << B)) continue;
+                    const double2 w = tw[m + ((v << (3 - B)) | (u32)(r >> (B + 1)))];
+                    const double X = x[r];
+                    const double T = modmul_q(x[r | (1 << B)], w.x, w.y, Q);
+                    x[r] = X + T;
+                    x[r | (1 << B)] = X - T;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) poly[phys(base | (u32)r)] = x[r];
+        }
+    }
+}
+
 // inverse NTT by one wave; |src| <= 0.6 Q bit-reversed; coefficient j = (r << 6) | lane in x[r], |x| <= 0.57 Q
 template <int LOGN>
 __device__ __forceinline__ void ntt_inverse_wave(const double* src, double* tmp, const double2* tw, u32 lane, double Q,
@@ -908,7 +977,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
         block_sync_lds();
         BCE_PROF_MARK(1);
         if constexpr (SPLIT) {
-            if (wave < R) ntt_forward_wave_low8<LOGN>(dct + wave * NP, tw, lane_v, Q);
+            forward_phase_balanced<LOGN>(dct, NP, tw, wave, lane_v, Q);
         } else {
             ntt_forward_wave<LOGN>(dct + wave * NP, tw, lane_v, Q);
         }
