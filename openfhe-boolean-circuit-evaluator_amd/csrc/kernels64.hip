@@ -493,6 +493,16 @@ using w64::block_sync_lds;
 using w64::for_each_index;
 using w64::gate_const;
 
+// Twiddle table access: entries [0, lds_n) are mirrored in LDS (the 8-wave N = 2048 kernel has room for the first
+// 1024 = every stage except the one on bit 0), the rest is read from global memory.  The block a stage uses
+// ([m, 2m), m a compile-time constant) lies entirely on one side.
+struct Tw {
+    const double2* __restrict__ g;   // global, [N]
+    const double2* l;                // LDS mirror of g[0 .. TW_LDS), or unused
+    template <u32 M, u32 TW_LDS>
+    __device__ __forceinline__ const double2* blk() const { return (2 * M <= TW_LDS) ? l : g; }
+};
+
 __device__ __forceinline__ double modmul_q(double y, double w, double wq, double Q) {  // wq = w / Q (rounded)
     const double h = y * w;
     const double l = fma(y, w, -h);
@@ -517,10 +527,11 @@ __device__ __forceinline__ void store_pass(double* poly, u32 lane, const double 
 #pragma unroll
     for (int r = 0; r < Cfg<LOGN>::E; ++r) poly[phys(elem_j<LOGN, LO>(lane, r))] = x[r];
 }
-template <int LOGN, int LO, int B>
-__device__ __forceinline__ void fwd_stage(double (&x)[Cfg<LOGN>::E], u32 lane, const double2* __restrict__ tw, double Q) {
+template <int LOGN, int LO, int B, u32 TWL>
+__device__ __forceinline__ void fwd_stage(double (&x)[Cfg<LOGN>::E], u32 lane, Tw twa, double Q) {
     constexpr int LE = Cfg<LOGN>::LE, E = Cfg<LOGN>::E, rb = B - LO;
     constexpr u32 m = 1u << (LOGN - 1 - B);
+    const double2* tw = twa.blk<m, TWL>();
     const u32 hi = (lane >> LO) << (LO + LE - B - 1);
 #pragma unroll
     for (int r = 0; r < E; ++r) {
@@ -533,10 +544,11 @@ __device__ __forceinline__ void fwd_stage(double (&x)[Cfg<LOGN>::E], u32 lane, c
     }
 }
 // psi^-k = -psi^(N-k): entry (2m-1) - i of the forward table, the sign goes into the operand (Y - X)
-template <int LOGN, int LO, int B>
-__device__ __forceinline__ void inv_stage(double (&x)[Cfg<LOGN>::E], u32 lane, const double2* __restrict__ tw, double Q) {
+template <int LOGN, int LO, int B, u32 TWL>
+__device__ __forceinline__ void inv_stage(double (&x)[Cfg<LOGN>::E], u32 lane, Tw twa, double Q) {
     constexpr int LE = Cfg<LOGN>::LE, E = Cfg<LOGN>::E, rb = B - LO;
     constexpr u32 m = 1u << (LOGN - 1 - B);
+    const double2* tw = twa.blk<m, TWL>();
     const u32 hi = (lane >> LO) << (LO + LE - B - 1);
 #pragma unroll
     for (int r = 0; r < E; ++r) {
@@ -547,23 +559,23 @@ __device__ __forceinline__ void inv_stage(double (&x)[Cfg<LOGN>::E], u32 lane, c
         x[r | (1 << rb)] = modmul_q(Y - X, f.x, f.y, Q);
     }
 }
-template <int LOGN, int LO, int BHI, int BLO>
-__device__ __forceinline__ void fwd_stages(double (&x)[Cfg<LOGN>::E], u32 lane, const double2* tw, double Q) {
+template <int LOGN, int LO, int BHI, int BLO, u32 TWL = 0>
+__device__ __forceinline__ void fwd_stages(double (&x)[Cfg<LOGN>::E], u32 lane, Tw tw, double Q) {
     if constexpr (BHI >= BLO) {
-        fwd_stage<LOGN, LO, BHI>(x, lane, tw, Q);
-        fwd_stages<LOGN, LO, BHI - 1, BLO>(x, lane, tw, Q);
+        fwd_stage<LOGN, LO, BHI, TWL>(x, lane, tw, Q);
+        fwd_stages<LOGN, LO, BHI - 1, BLO, TWL>(x, lane, tw, Q);
     }
 }
-template <int LOGN, int LO, int BLO, int BHI>
-__device__ __forceinline__ void inv_stages(double (&x)[Cfg<LOGN>::E], u32 lane, const double2* tw, double Q) {
+template <int LOGN, int LO, int BLO, int BHI, u32 TWL = 0>
+__device__ __forceinline__ void inv_stages(double (&x)[Cfg<LOGN>::E], u32 lane, Tw tw, double Q) {
     if constexpr (BLO <= BHI) {
-        inv_stage<LOGN, LO, BLO>(x, lane, tw, Q);
-        inv_stages<LOGN, LO, BLO + 1, BHI>(x, lane, tw, Q);
+        inv_stage<LOGN, LO, BLO, TWL>(x, lane, tw, Q);
+        inv_stages<LOGN, LO, BLO + 1, BHI, TWL>(x, lane, tw, Q);
     }
 }
 // forward NTT by one wave in LDS; |input| <= Q, |output| < 7 Q, bit-reversed order
 template <int LOGN>
-__device__ __forceinline__ void ntt_forward_wave(double* poly, const double2* tw, u32 lane, double Q) {
+__device__ __forceinline__ void ntt_forward_wave(double* poly, Tw tw, u32 lane, double Q) {
     using C = Cfg<LOGN>;
     double x[C::E];
     load_pass<LOGN, 6>(poly, lane, x);
@@ -583,7 +595,7 @@ __device__ __forceinline__ void ntt_forward_wave(double* poly, const double2* tw
 }
 // forward NTT (N = 2048) whose stages on bits 10, 9, 8 were already applied by the producer: bits 7..3, then 2..0
 template <int LOGN>
-__device__ __forceinline__ void ntt_forward_wave_low8(double* poly, const double2* tw, u32 lane, double Q) {
+__device__ __forceinline__ void ntt_forward_wave_low8(double* poly, Tw tw, u32 lane, double Q) {
     static_assert(LOGN == 11, "laid out for N = 2048");
     double x[Cfg<LOGN>::E];
     load_pass<LOGN, 3>(poly, lane, x);
@@ -602,18 +614,18 @@ __device__ __forceinline__ void ntt_forward_wave_low8(double* poly, const double
 // then 3..0): every SIMD carries 1.5 transforms.  The two passes are separated by ONE workgroup barrier (the half
 // transforms exchange data across two waves), which every wave executes.
 template <int LOGN>
-__device__ __forceinline__ void forward_phase_balanced(double* dct, int NP, const double2* __restrict__ tw, u32 wave, u32 lane,
-                                                       double Q) {
+__device__ __forceinline__ void forward_phase_balanced(double* dct, int NP, Tw twa, u32 wave, u32 lane, double Q) {
+    constexpr u32 TWL = 1024;
     static_assert(LOGN == 11, "laid out for N = 2048, 6 polynomials on 8 waves");
     if (wave < 4) {
         double* poly = dct + wave * NP;
         double x[Cfg<LOGN>::E];
         load_pass<LOGN, 3>(poly, lane, x);
-        fwd_stages<LOGN, 3, 7, 3>(x, lane, tw, Q);
+        fwd_stages<LOGN, 3, 7, 3, TWL>(x, lane, twa, Q);
         store_pass<LOGN, 3>(poly, lane, x);
         block_sync_lds();
         load_pass<LOGN, 0>(poly, lane, x);
-        fwd_stages<LOGN, 0, 2, 0>(x, lane, tw, Q);
+        fwd_stages<LOGN, 0, 2, 0, TWL>(x, lane, twa, Q);
         store_pass<LOGN, 0>(poly, lane, x);
     } else {
         double* poly = dct + (4 + (wave & 1u)) * NP;
@@ -627,6 +639,7 @@ __device__ __forceinline__ void forward_phase_balanced(double* dct, int NP, cons
             for (int B = 7; B >= 4; --B) {           // stage on bit B = register bit B - 4; twiddle tw[m + (p >> (B+1))]
                 const int rb = B - 4;
                 const u32 m = 1u << (10 - B);
+                const double2* tw = twa.l;  // m <= 64: LDS mirror
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (r & (1 << rb)) continue;
@@ -648,6 +661,7 @@ __device__ __forceinline__ void forward_phase_balanced(double* dct, int NP, cons
 #pragma unroll
             for (int B = 3; B >= 0; --B) {
                 const u32 m = 1u << (10 - B);
+                const double2* tw = (B == 0) ? twa.g : twa.l;  // only the block of the last stage (m = 1024) is global
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (r & (1 << B)) continue;
@@ -666,7 +680,7 @@ __device__ __forceinline__ void forward_phase_balanced(double* dct, int NP, cons
 
 // inverse NTT by one wave; |src| <= 0.6 Q bit-reversed; coefficient j = (r << 6) | lane in x[r], |x| <= 0.57 Q
 template <int LOGN>
-__device__ __forceinline__ void ntt_inverse_wave(const double* src, double* tmp, const double2* tw, u32 lane, double Q,
+__device__ __forceinline__ void ntt_inverse_wave(const double* src, double* tmp, Tw tw, u32 lane, double Q,
                                                  double2 ninv, double (&x)[Cfg<LOGN>::E]) {
     using C = Cfg<LOGN>;
     constexpr int LE = C::LE;
@@ -724,15 +738,15 @@ __device__ __forceinline__ void inv_pass8(double (&x)[8], const double2 (&f0)[4]
 }
 // inverse twiddle of stage B for stage index i: -tw[(2m - 1) - i], m = 2^(LOGN-1-B); the sign sits in the operand
 template <int B>
-__device__ __forceinline__ double2 itw11(const double2* __restrict__ tw, u32 i) {
+__device__ __forceinline__ double2 itw11(Tw tw, u32 i) {
     constexpr u32 m = 1u << (10 - B);
-    return tw[(2 * m - 1) - i];
+    return tw.blk<m, 1024>()[(2 * m - 1) - i];
 }
 // acc: evaluation-form polynomial (padded natural layout); bufA / bufB: >= 2112 doubles each; t = thread in the
 // 256-thread group.  Leaves coefficient j = (r << 8) | t in x[r] (before the N^-1 scaling).  4 workgroup barriers;
 // bufA must not be written by anyone until the caller's next barrier (pass 3 reads it).
-__device__ __forceinline__ void split_inverse11(const double* src, double* bufA, double* bufB, const double2* __restrict__ tw,
-                                                u32 t, double Q, double (&x)[8]) {
+__device__ __forceinline__ void split_inverse11(const double* src, double* bufA, double* bufB, Tw tw, u32 t, double Q,
+                                                double (&x)[8]) {
     double2 f0[4], f1[2], f2;
     {   // pass 0: p = 8t + r
         const double2* sp = reinterpret_cast<const double2*>(src + phys(8 * t));
@@ -808,6 +822,11 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
     double* dct = acc + 2 * NP;   // [R][NP]
     u32* av = reinterpret_cast<u32*>(dct + R * NP);
     const double2* __restrict__ tw = P.tw64d;
+    // LDS mirror of the first 1024 twiddle entries (8-wave kernel only: 16 KiB of the 20 KiB left next to the polynomials)
+    double2* twl = reinterpret_cast<double2*>(av + ((P.n + 1 + 3) & ~3u));
+    if constexpr (SPLIT)
+        for (u32 i = threadIdx.x; i < 1024u; i += 512u) twl[i] = tw[i];
+    const Tw twa{tw, twl};
 
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double Q = P.Qd, invQ = P.invQd;
@@ -849,7 +868,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
         }
     }
     __syncthreads();
-    if (wave == 0) ntt_forward_wave<LOGN>(acc + NP, tw, lane, Q);
+    if (wave == 0) ntt_forward_wave<LOGN>(acc + NP, Tw{tw, nullptr}, lane, Q);
     __syncthreads();
     for (u32 j = tid; j < (u32)N; j += T) acc[NP + phys(j)] = modred(acc[NP + phys(j)], invQ, Q);
     __syncthreads();
@@ -912,7 +931,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
             const u32 c = wave >> 2, t = tid_v & 255u;
             double x[8];
             // exchange buffers live in dct rows 0..3 (dead until the digits are written)
-            split_inverse11(acc + c * NP, dct + c * NP, dct + (2 + c) * NP, tw, t, Q, x);
+            split_inverse11(acc + c * NP, dct + c * NP, dct + (2 + c) * NP, twa, t, Q, x);
             block_sync_lds();  // every thread has read its pass-3 inputs: the digit rows may be overwritten
             // digits, then the first three FORWARD stages (bits 10, 9, 8 = this thread's register index) on each digit
             // in registers: the forward transform below is left with bits 7..0 (two passes)
@@ -924,7 +943,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
                 d = d < dlo ? d + Q : d;
                 u[r] = d + doff;
             }
-            const double2 w10 = tw[1], w9a = tw[2], w9b = tw[3];
+            const double2 w10 = twl[1], w9a = twl[2], w9b = twl[3];
 #pragma unroll
             for (u32 l = 0; l < (u32)DG; ++l) {
                 double v[8];
@@ -948,7 +967,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {  // bit 8: (2k, 2k+1), twiddle tw[4 + k]
-                    const double2 w = tw[4 + k];
+                    const double2 w = twl[4 + k];
                     const double T = modmul_q(v[2 * k + 1], w.x, w.y, Q);
                     v[2 * k + 1] = v[2 * k] - T; v[2 * k] = v[2 * k] + T;
                 }
@@ -957,7 +976,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
             }
         } else if (wave < 2) {
             double x[E];
-            ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, tw, lane_v, Q, ninv, x);
+            ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, Tw{tw, nullptr}, lane_v, Q, ninv, x);
 #pragma unroll
             for (int r = 0; r < E; ++r) {
                 double d = x[r];
@@ -977,9 +996,9 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
         block_sync_lds();
         BCE_PROF_MARK(1);
         if constexpr (SPLIT) {
-            forward_phase_balanced<LOGN>(dct, NP, tw, wave, lane_v, Q);
+            forward_phase_balanced<LOGN>(dct, NP, twa, wave, lane_v, Q);
         } else {
-            ntt_forward_wave<LOGN>(dct + wave * NP, tw, lane_v, Q);
+            ntt_forward_wave<LOGN>(dct + wave * NP, Tw{tw, nullptr}, lane_v, Q);
         }
         BCE_PROF_MARK(2);
         block_sync_lds();
@@ -1043,7 +1062,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
     if constexpr (SPLIT) {
         const u32 c = wave >> 2, t = tid & 255u;
         double x[8];
-        split_inverse11(acc + c * NP, dct + c * NP, dct + (2 + c) * NP, tw, t, Q, x);
+        split_inverse11(acc + c * NP, dct + c * NP, dct + (2 + c) * NP, twa, t, Q, x);
         u64* out = acc_out + ((size_t)blockIdx.x * 2 + c) * N;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -1054,7 +1073,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
         }
     } else if (wave < 2) {
         double x[E];
-        ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, tw, lane, Q, ninv, x);
+        ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, Tw{tw, nullptr}, lane, Q, ninv, x);
         u64* out = acc_out + ((size_t)blockIdx.x * 2 + wave) * N;
 #pragma unroll
         for (int r = 0; r < E; ++r) {
@@ -1118,7 +1137,8 @@ hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32
         kern = ap ? w64::k_blind_rotate64<9, 4, true> : w64::k_blind_rotate64<9, 4, false>;
     }
     if (!kern) return hipErrorInvalidValue;
-    const size_t lds = blind_rotate64_lds_bytes(P);
+    // the 8-wave double-precision kernel also mirrors the first 1024 twiddle entries (16 KiB) in LDS
+    const size_t lds = blind_rotate64_lds_bytes(P) + ((P.fp64 && threads == 512) ? 1024 * sizeof(double2) : 0);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_desc * instances), dim3(threads), lds, s, P, d, n_desc, slot_stride, acc_out);
