@@ -10,6 +10,12 @@ rank per GPU under torch.distributed.run): keys replicated from the same seed, i
 over ranks (weak scaling, K per GPU), RCCL used only to exchange the final outputs
 (`--shard gates` instead shards every frontier and exchanges boundary ciphertexts over RCCL).
 
+`python3 bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) starts the N ranks itself: the parent
+spawns N fresh child processes of this script BEFORE anything touches the GPU (it never does itself), forwards
+rank 0's JSON line and exits non-zero if any child fails.  With N > 1 the line also carries a `shard_gates`
+object: the same circuit with every frontier's gates split over the ranks (north_star's partition, strong
+scaling, one allgather of boundary ciphertexts per level), timed over a few steps after the headline run.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -77,6 +83,33 @@ def cpu_baseline(seconds_budget=20.0):
                       "OpenMP over gates on %d threads, %.1f s; CPU restatement of the OpenFHE algorithm, not OpenFHE" % (nb, cores, dt)}
 
 
+def spawn_ranks(n, argv):
+    """Parent of a self-launched multi-GPU run: N child processes of this script, one rank per GPU, rendezvous
+    on 127.0.0.1.  The parent never initialises the GPU (no torch import, no HIP call) and never execs."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        sys.exit(1)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,7 +126,11 @@ def main():
     ap.add_argument("--xor-fast", action="store_true", help="opt-in native XOR (NOT the reference's XOR = 3 bootstraps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--gates-steps", type=int, default=2, help="N > 1: timed steps of the secondary gate-sharded run (0 = skip)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])      # does not return
 
     import torch
     bce = importlib.import_module("openfhe-boolean-circuit-evaluator_amd")
@@ -103,127 +140,197 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     # test-only knobs (a one-GPU box rehearsing the N > 1 path): all ranks on device 0, gloo instead of RCCL
     if os.environ.get("BCE_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
     backend = os.environ.get("BCE_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
+        if backend != "nccl":   # host-side rendezvous needs no GPU: do it first, so that start-up problems show as such
             dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.barrier()
+            sys.stderr.write("bench.py: rank %d/%d rendezvous ok (%s)\n" % (rank, world, backend))
+    if not torch.cuda.is_available():
+        if dist is not None and dist.is_initialized():
+            dist.destroy_process_group()
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1 and backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        sys.stderr.write("bench.py: rank %d/%d rendezvous ok (nccl = RCCL)\n" % (rank, world))
     red_dev = "cuda" if backend == "nccl" else "cpu"  # where the few scalars of the result are reduced
 
     # ---- setup (untimed): context, keys (same seed on every rank = replicated), circuit, inputs
     t_setup = time.time()
     cc = bce.BinFHEContext(getattr(bce, args.paramset), bce.GINX, device=local_rank)
-    cc.KeyGen(0x0FE5EED)
-    circ = bce.Circuit(cc)
+    t_kg = time.time()
+    cc.KeyGen(0x0FE5EED)            # explicit seed: the SAME key set on every rank (synthetic benchmark keys)
+    keygen_s = time.time() - t_kg
     path = os.path.join(ROOT, "tests", "golden", "circuits", args.circuit)
-    circ.ReadBristol(path, new_flag=args.circuit.startswith("sha256_new"))
-    if args.xor_fast:
-        circ.setXorFast(True)
-    shard_mode = 0 if args.shard == "instances" else 1
-    if args.relevel and world > 1 and shard_mode == 1:
-        args.relevel = False  # the bootstrap-depth schedule is not defined for gate sharding: reference gate levels
-    if args.relevel:
-        circ.setRelevel(True)
-    info = circ.info()
-    # instances (default, weak scaling): every rank evaluates ITS OWN K input blocks with its own circuit object --
-    # independent units, no data-path collective at all (only the barrier / reductions of this script).
-    # gates: one set of K blocks, every level's gates split over the ranks, boundary ciphertexts exchanged (RCCL).
     K_total = args.instances
-    circ.setInstances(K_total)
-    xch = None
-    if world > 1 and shard_mode == 1:
-        from importlib import import_module
-        xch = import_module("openfhe-boolean-circuit-evaluator_amd.dist").Exchange(
-            circ, shard_mode, encrypted=True, device=torch.device("cuda", local_rank))
-    rng = np.random.default_rng(12345 + (rank if shard_mode == 0 else 0))
-    widths = info["n_input_bits"]
-    inputs = []
-    for k in range(K_total):
-        if args.circuit == "AES-expanded.txt" and k < 2:  # the reference's two vectors first
-            v = [x for x in kat.AES_VECTORS if x["circuit"] == "AES-expanded"][k]
-            inputs.append(kat.aes_case(v)[0])
-        else:
-            inputs.append([rng.integers(0, 2, w).tolist() for w in widths])
-    # plaintext pass = expected outputs
-    circ.Reset()
-    circ.setPlaintext(True)
-    for k in range(K_total):
-        circ.SetInput(inputs[k], instance=k)
-    circ.Clock()
-    expect = [circ.Outputs(k)[0] for k in range(K_total)]
-    circ.Reset()
-    circ.setEncrypted(True)
-    for k in range(K_total):
-        circ.SetInput(inputs[k], instance=k)
-    cc.synchronize()
-    setup_s = time.time() - t_setup
 
-    def step():
-        circ.Rearm()
+    def run_mode(shard_mode, steps, warmup, relevel):
+        """One timed run.  shard_mode 0 (instances): every rank evaluates ITS OWN K input blocks with its own
+        circuit object -- independent units, no data-path collective (only the barrier / reductions of this
+        script).  shard_mode 1 (gates): ONE set of K blocks, every level's gates split over the ranks by bootstrap
+        weight, boundary ciphertexts exchanged per level (RCCL allgather)."""
+        circ = bce.Circuit(cc)
+        circ.ReadBristol(path, new_flag=args.circuit.startswith("sha256_new"))
+        if args.xor_fast:
+            circ.setXorFast(True)
+        gates = world > 1 and shard_mode == 1
+        if gates:
+            relevel = False        # the bootstrap-depth schedule is not defined for gate sharding: reference gate levels
+            cc.set_encrypt_seed(0x0FE5EED)   # every rank must encrypt IDENTICAL input ciphertexts
+        if relevel:
+            circ.setRelevel(True)
+        info = circ.info()
+        circ.setInstances(K_total)
+        xch = None
+        if gates:
+            xch = importlib.import_module("openfhe-boolean-circuit-evaluator_amd.dist").Exchange(
+                circ, 1, encrypted=True, device=torch.device("cuda", local_rank))
+        rng = np.random.default_rng(12345 + (0 if gates else rank))
+        widths = info["n_input_bits"]
+        inputs = []
+        for k in range(K_total):
+            if args.circuit == "AES-expanded.txt" and k < 2:  # the reference's two vectors first
+                v = [x for x in kat.AES_VECTORS if x["circuit"] == "AES-expanded"][k]
+                inputs.append(kat.aes_case(v)[0])
+            else:
+                inputs.append([rng.integers(0, 2, w).tolist() for w in widths if w])
+        # plaintext pass = expected outputs (host logic only; under gate sharding it runs the same exchange plan on bits)
+        circ.Reset()
+        circ.setPlaintext(True)
+        for k in range(K_total):
+            circ.SetInput(inputs[k], instance=k)
         circ.Clock()
+        expect = [circ.Outputs(k)[0] for k in range(K_total)]
+        circ.Reset()
+        circ.setEncrypted(True)
+        for k in range(K_total):
+            circ.SetInput(inputs[k], instance=k)
+        cc.synchronize()
+        t_ready = time.time()
 
-    for _ in range(args.warmup):
-        step()
-    cc.synchronize()
-    cc.timing_reset()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(args.steps):
-        step()
-    cc.synchronize()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.time() - t0
-    tm = cc.timing()
-    my_boot = tm["bootstraps"]
-    # correctness of the timed work: decrypted outputs of every instance == plaintext evaluation
-    got = [circ.Outputs(k)[0] for k in range(K_total)]
-    verified = got == expect
-    if dist is not None:
-        t = torch.tensor([elapsed, float(my_boot), 0.0 if verified else 1.0], dtype=torch.float64, device=red_dev)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        total_boot = float(t[1])
-        verified = float(tmax[2]) == 0.0      # every rank's outputs
-    else:
-        total_boot = float(my_boot)
-    st = circ.stats()
+        def step():
+            circ.Rearm()
+            circ.Clock()
 
-    traffic = None
-    try:  # HBM/fabric bytes per launch from the committed --pmc passes of this same default command
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")))
-        if (args.instances == tj.get("instances_per_gpu") and args.circuit == "AES-expanded.txt" and args.paramset == "STD128_OPT"
-                and shard_mode == 0 and args.relevel == tj.get("relevel") and not args.xor_fast):
-            traffic = tj  # used below only if it was measured on the kernel that dominates this run
-    except Exception:
-        pass
+        for _ in range(warmup):
+            step()
+        cc.synchronize()
+        cc.timing_reset()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(steps):
+            step()
+        cc.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.time() - t0
+        tm = cc.timing()
+        # correctness of the timed work: decrypted outputs of every instance == plaintext evaluation
+        verified = [circ.Outputs(k)[0] for k in range(K_total)] == expect
+        st = circ.stats()
+        total_boot = float(tm["bootstraps"])
+        if dist is not None:
+            t = torch.tensor([elapsed, total_boot, 0.0 if verified else 1.0, float(st["exchanged_cts"])], dtype=torch.float64, device=red_dev)
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            elapsed = float(tmax[0])
+            total_boot = float(t[1])
+            verified = float(tmax[2]) == 0.0      # every rank's outputs
+            xcts = float(t[3])
+        else:
+            xcts = 0.0
+        if gates:
+            cc.set_encrypt_seed(None)
+        circ.close()
+        return {"elapsed": elapsed, "total_boot": total_boot, "verified": verified, "tm": tm, "info": info, "relevel": relevel,
+                "exchanges_per_step": st["exchanges"], "exchanged_cts_per_step": xcts, "steps": steps, "t_ready": t_ready}
+
+    shard_mode = 0 if args.shard == "instances" else 1
+    R = run_mode(shard_mode, args.steps, args.warmup, args.relevel)
+    setup_s = R["t_ready"] - t_setup     # context + keygen + parsing + plaintext pass + input encryption
+    G = None
+    if world > 1 and shard_mode == 0 and args.gates_steps > 0:
+        G = run_mode(1, args.gates_steps, 1, False)
+    elapsed, total_boot, verified, tm, info = R["elapsed"], R["total_boot"], R["verified"], R["tm"], R["info"]
+
+    def load_profile(name):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            return None
+
+    default_cmd = (args.instances == 32 and args.circuit == "AES-expanded.txt" and args.paramset == "STD128_OPT"
+                   and shard_mode == 0 and R["relevel"] and not args.xor_fast)
     if rank == 0:
-        bpb = cc.bytes_per_bootstrap()
+        parts = cc.bytes_per_bootstrap_parts()         # {"bsk", "ksk", "ct"} at this build's widths (SURVEY 8(d) formula)
+        bpb = parts["bsk"] + parts["ksk"] + parts["ct"]
         pr = cc.params
         bsk_once = 4 * pr["n"] * 2 * (2 * pr["dG"]) * 2 * pr["N"]   # u32 GINX key, read once if perfectly shared
         # roofline of the DOMINANT blind-rotation kernel of this run (launch size picks between kernels)
         dom = max(tm["by_kernel"], key=lambda k: k["ms"])
         br_s = dom["ms"] / 1e3
-        achieved = (bpb * dom["bootstraps"] / br_s) / 1e9 if br_s > 0 else 0.0
+        per_launch = dom["bootstraps"] / max(1, dom["launches"])
+        avg_launch_ms = dom["ms"] / max(1, dom["launches"])
+        br_bytes = parts["bsk"] + parts["ct"]             # what the blind-rotation kernel itself reads / writes per bootstrap
+        achieved = (br_bytes * dom["bootstraps"] / br_s) / 1e9 if br_s > 0 else 0.0
+        tail_s = tm["tail_ms"] / 1e3
+        tail_achieved = (parts["ksk"] * tm["bootstraps"] / tail_s) / 1e9 if tail_s > 0 else 0.0
+        # committed PMC passes of this same default command / of one saturated launch of this kernel
+        # (rocprofv3 cannot run inside the timed region: these are REPLAYED constants, named with their files)
+        traffic = load_profile("r02_pmc_traffic.json") if default_cmd else None
+        valu = load_profile("r02_valu_model.json")
+        roof = {
+            "bound": "hbm", "kernel": dom["kernel"],
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic["hbm_bytes_per_launch"] if traffic and traffic.get("bench_kernel") == dom["kernel"] else None,
+            "traffic_source": "profiles/r02_pmc_traffic.json: bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of "
+                              "this default command, tools/collect_evidence.sh) -- a committed constant replayed here, NOT measured in this run",
+            "bytes_per_bootstrap": {"blind_rotation (u32 BSK rows + u32 ct in/acc out)": br_bytes, "tail (u16 KSK rows)": parts["ksk"], "total": bpb},
+            "algorithmic_bytes_per_launch": br_bytes * per_launch,
+            # SURVEY 8(d): the key is reused from cache across a batch, so also the compulsory bytes of a launch:
+            # the key once + per-bootstrap ciphertext / accumulator I/O
+            "compulsory_bytes_per_launch": bsk_once + parts["ct"] * per_launch,
+            "bootstraps_per_launch": per_launch,
+            "avg_launch_ms": avg_launch_ms,
+            "launches": dom["launches"],
+            "share_of_blind_rotation_time": dom["ms"] / max(1e-9, tm["blind_rotate_ms"]),
+            "other_blind_rotation_kernels": [k for k in tm["by_kernel"] if k is not dom and k["launches"]],
+            "tail": {"kernel": "k_tail_gather + k_tail_finish", "bound": "hbm", "ms_total": tm["tail_ms"],
+                     "avg_launch_ms": tm["tail_ms"] / max(1, tm["blind_rotate_launches"]),
+                     "achieved": tail_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tail_achieved / HBM_PEAK_GBS,
+                     "traffic": (traffic or {}).get("tail_hbm_bytes_per_launch"),
+                     "note": "KSK row gather: algorithmic = N*dKS rows of (n+1) u16 per bootstrap; rows come from the 256 MiB table "
+                             "(Infinity-Cache sized), so the fabric counters see them"},
+            "note": "achieved = algorithmic bytes of the blind-rotation kernel (u32 BSK rows + ct I/O per bootstrap) x bootstraps / its "
+                    "time from HIP events on the engine stream.  The 62.8 MiB key is served from L2 / Infinity Cache across the "
+                    "batch (compulsory << algorithmic), so this fraction can exceed 1 and does not bind; the binding roof is "
+                    "integer-VALU issue: see `valu`",
+        }
+        if valu and valu.get("bench_kernel") == dom["kernel"]:
+            # VALU roof: wave-instructions per bootstrap (SQ_INSTS_VALU of one saturated launch, committed PMC pass) x the
+            # measured issue cost per wave-instruction per SIMD of this kernel's instruction mix (tools/valu_rates.hip,
+            # tools/valu_model.py) / SIMDs of the chip = the time the launch needs at 100 % VALU issue
+            simds = 4 * (valu.get("cu_count") or 256)
+            floor_ms = valu["valu_insts_per_bootstrap"] * per_launch * valu["ns_per_wave_inst_per_simd"] / simds / 1e6
+            roof["valu"] = {"bound": "integer VALU issue", "insts_per_bootstrap": valu["valu_insts_per_bootstrap"],
+                            "ns_per_wave_inst_per_simd": valu["ns_per_wave_inst_per_simd"], "simds": simds,
+                            "floor_ms_per_launch": floor_ms, "avg_launch_ms": avg_launch_ms, "frac": floor_ms / avg_launch_ms if avg_launch_ms else None,
+                            "source": "profiles/r02_valu_model.json (SQ_INSTS_VALU pass + instruction mix of the ISA + measured issue "
+                                      "costs; committed constants, the launch time is this run's)"}
+            roof["frac_valu"] = roof["valu"]["frac"]
         out = {
             "metric": METRIC,
             "value": total_boot / elapsed,
@@ -243,38 +350,34 @@ def main():
                                 args.circuit, info["n_gates"] - info["n_output_bits"], info["n_bootstraps"],
                                 info["n_sublaunches"], args.paramset, args.instances),
                 "instances_per_gpu": args.instances, "sharding": args.shard,
-                "schedule": "bootstrap-depth levels (NOTs folded, identical ciphertexts)" if args.relevel else "gate levels (reference Clock rounds)",
+                "schedule": "bootstrap-depth levels (NOTs folded, identical ciphertexts)" if R["relevel"] else "gate levels (reference Clock rounds)",
                 "xor": "XOR_FAST (opt-in, 1 bootstrap)" if args.xor_fast else "NOT,NOT,AND,AND,OR (reference, 3 bootstraps)",
                 "bootstraps_per_step": int(total_boot / args.steps),
-                "outputs_verified": bool(verified), "setup_s": round(setup_s, 2),
+                "outputs_verified": bool(verified), "setup_s": round(setup_s, 2), "keygen_s": round(keygen_s, 2),
                 "host_share_of_step": round(1.0 - (tm["blind_rotate_ms"] + tm["tail_ms"]) / (elapsed * 1e3), 4),
+                "exchanges_per_step": R["exchanges_per_step"], "exchanged_cts_per_step": R["exchanged_cts_per_step"],
+                "collective": "none in the timed region (independent input blocks per rank)" if shard_mode == 0 else
+                              "one allgather of boundary ciphertexts per level (%s)" % backend,
             },
-            "roofline": {
-                "bound": "hbm", "kernel": dom["kernel"],
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic["hbm_bytes_per_launch"] if traffic and traffic.get("bench_kernel") == dom["kernel"] else None,
-                "traffic_unit": "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes, profiles/r01b_pmc_traffic.json)",
-                "algorithmic_bytes_per_launch": bpb * dom["bootstraps"] / max(1, dom["launches"]),
-                "bytes_per_bootstrap": bpb,
-                # when the key is reused from cache across a batch, also state the compulsory
-                # bytes of a launch: the key once + per-bootstrap key-switch rows and ciphertext I/O
-                "compulsory_bytes_per_launch": bsk_once + (bpb - bsk_once) * dom["bootstraps"] / max(1, dom["launches"]),
-                "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
-                "launches": dom["launches"],
-                "share_of_blind_rotation_time": dom["ms"] / max(1e-9, tm["blind_rotate_ms"]),
-                "other_blind_rotation_kernels": [k for k in tm["by_kernel"] if k is not dom and k["launches"]],
-                "tail_kernel_ms_total": tm["tail_ms"],
-                "note": "achieved = algorithmic bytes (u32 BSK + u16 KSK rows + u32 cts per bootstrap) x bootstraps / "
-                        "blind-rotation kernel time from HIP events on the engine stream; the 62.8 MiB BSK is mostly served "
-                        "from L2 / Infinity Cache (traffic << algorithmic), so frac can approach or exceed 1; the kernel is "
-                        "bound by integer VALU issue and LDS, not by HBM (DESIGN.md section 4)",
-            },
+            "roofline": roof,
         }
+        if G is not None:
+            out["shard_gates"] = {
+                "what": "the same circuit and K, every level's gates split over the %d ranks by bootstrap weight (north_star's partition); "
+                        "boundary ciphertexts exchanged with one allgather per level (%s); reference gate-level schedule" % (world, backend),
+                "value": G["total_boot"] / G["elapsed"], "unit": "gate-bootstraps/s", "scaling": "strong",
+                "ms_per_step": G["elapsed"] / G["steps"] * 1e3, "steps": G["steps"], "warmup": 1,
+                "exchanges_per_step": G["exchanges_per_step"], "exchanged_cts_per_step": G["exchanged_cts_per_step"],
+                "outputs_verified": bool(G["verified"]),
+            }
+            verified = verified and G["verified"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         if not verified:
             out["error"] = "decrypted outputs differ from the plaintext evaluation"
         print(json.dumps(out), flush=True)
+    elif G is not None:
+        verified = verified and G["verified"]
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

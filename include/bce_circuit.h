@@ -34,6 +34,7 @@ typedef struct bce_circuit_info {
     uint32_t n_sublaunches;  /* dependent bce_eval_gates launches per evaluation          */
     uint32_t n_relevel_steps;/* dependent launches of the opt-in re-levelled schedule     */
     uint32_t max_frontier;   /* widest sub-launch, in bootstraps                          */
+    uint32_t slot_stride;    /* pool slots per instance: register r of instance k = slot k*slot_stride + r */
     uint64_t n_bootstraps;   /* per evaluation: AND=1, OR=1, XOR=3, NOT=0                 */
 } bce_circuit_info;
 

@@ -97,9 +97,14 @@ const char* bce_last_error(const bce_ctx*);
 int bce_get_params(const bce_ctx*, uint64_t out[BCE_P_COUNT]);
 
 /* ---- keys -------------------------------------------------------------- */
-/* sk = cc.KeyGen(); cc.BTKeyGen(sk): src/circuit.cpp:90-91.  Deterministic from
- * a 32-byte seed (ChaCha20 streams, DESIGN.md "PRNG spec"); RGSW rows are
- * transformed and multiplied by the ring key on the device. */
+/* sk = cc.KeyGen(); cc.BTKeyGen(sk): src/circuit.cpp:90-91.
+ * seed == NULL (what a drop-in caller passes): the 32-byte seed comes from the
+ * operating system's entropy pool, as OpenFHE's KeyGen draws from its own
+ * entropy-seeded PRNG.  An explicit seed makes the keys a deterministic function
+ * of it (ChaCha20 streams, DESIGN.md "PRNG spec") -- for the oracle parity tests
+ * and for replicating one key set on every rank of a multi-GPU run; whoever passes
+ * one owns its secrecy.  RGSW rows are transformed and multiplied by the ring key
+ * on the device. */
 int bce_keygen(bce_ctx*, const uint8_t seed[32]);
 /* canonical exchange format = coefficient domain, u64 words (what an OpenFHE
  * export would be converted to): s[n], z[N] in {-1,0,1}; bsk [i][key][row][col][N]
@@ -121,10 +126,22 @@ int bce_lwe_write(bce_ctx*, const uint32_t* slots, uint32_t count, const uint64_
 int bce_lwe_read(bce_ctx*, const uint32_t* slots, uint32_t count, uint64_t* cts);
 
 /* cc.Encrypt(sk, bit): src/circuit.cpp:506, src/gate.cpp:118,139,143,158,179,211.
- * Ciphertext k uses PRNG stream enc_index_base + k.  BCE_BOOTSTRAPPED also runs
- * Bootstrap(ct) on the device as OpenFHE v1.0.x does by default. */
+ * The mask a and the noise e of every ciphertext come from a ChaCha20 stream keyed
+ * with the context's ENCRYPTION seed, which is independent of the key seed: it is
+ * drawn from OS entropy when the context is created, and the stream number is a
+ * per-context counter that only moves forward -- `enc_index_base` is then IGNORED,
+ * so no (a, e) pair can repeat whatever the caller passes (also after
+ * bce_import_keys).  BCE_BOOTSTRAPPED also runs Bootstrap(ct) on the device as
+ * OpenFHE v1.0.x does by default. */
 int bce_encrypt_bits(bce_ctx*, const uint8_t* bits, const uint32_t* slots, uint32_t count,
                      uint64_t enc_index_base, int mode);
+/* Test / replication mode of bce_encrypt_bits: with an explicit 32-byte seed,
+ * ciphertext k of a call uses stream `enc_index_base + k` of that seed, so that
+ * (1) the oracle reproduces the ciphertext bit for bit and (2) every rank of a
+ * gate-sharded multi-GPU run encrypts identical inputs.  The caller then owns the
+ * uniqueness of the indices: reusing one reuses (a, e).  seed == NULL returns to
+ * the default (fresh OS entropy, internal counter). */
+int bce_set_encrypt_seed(bce_ctx*, const uint8_t seed[32]);
 /* cc.Decrypt(sk, ct, &res): src/circuit.cpp:800, src/gate.cpp:72,97,115,... (res in 0..3) */
 int bce_decrypt_bits(bce_ctx*, const uint32_t* slots, uint32_t count, uint8_t* bits);
 
@@ -148,6 +165,9 @@ int bce_timing_get(bce_ctx*, bce_timing* out); /* synchronizes */
 /* algorithmic bytes one gate-bootstrap reads at the widths this engine ships
  * (SURVEY.md 8(d) formula with w_bsk, w_ks, w_ct of this build) */
 uint64_t bce_bytes_per_bootstrap(const bce_ctx*);
+/* the same figure split by the kernel that moves the bytes: out[0] = bootstrapping-key rows (blind rotation),
+ * out[1] = key-switching-key rows (tail gather), out[2] = ciphertext input / output words */
+int bce_bytes_per_bootstrap_parts(const bce_ctx*, uint64_t out[3]);
 
 /* ---- staged outputs for parity tests ----------------------------------- */
 /* Runs the frontier like bce_eval_gates and also returns the intermediates

@@ -55,8 +55,8 @@ ENGINE_SYMBOLS = [
     "bce_ctx_create", "bce_ctx_create_custom", "bce_ctx_destroy", "bce_last_error", "bce_get_params",
     "bce_keygen", "bce_import_keys", "bce_bsk_words", "bce_ksk_words", "bce_export_sk", "bce_export_bsk",
     "bce_export_ksk", "bce_pool_reserve", "bce_pool_slots", "bce_lwe_write", "bce_lwe_read",
-    "bce_encrypt_bits", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize",
-    "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_debug_eval_stages", "bce_debug_ntt",
+    "bce_encrypt_bits", "bce_set_encrypt_seed", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize",
+    "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_debug_eval_stages", "bce_debug_ntt",
 ]
 
 _lib = None
@@ -99,6 +99,7 @@ def lib():
     L.bce_lwe_write.argtypes = [vp, vp, u32, vp]
     L.bce_lwe_read.argtypes = [vp, vp, u32, vp]
     L.bce_encrypt_bits.argtypes = [vp, vp, vp, u32, u64, i32]
+    L.bce_set_encrypt_seed.argtypes = [vp, C.c_char_p]
     L.bce_decrypt_bits.argtypes = [vp, vp, u32, vp]
     L.bce_eval_gates.argtypes = [vp, u32, vp]
     L.bce_eval_gates_strided.argtypes = [vp, u32, vp, u32, u32]
@@ -107,6 +108,7 @@ def lib():
     L.bce_timing_get.argtypes = [vp, C.POINTER(Timing)]
     L.bce_bytes_per_bootstrap.argtypes = [vp]
     L.bce_bytes_per_bootstrap.restype = u64
+    L.bce_bytes_per_bootstrap_parts.argtypes = [vp, C.POINTER(u64)]
     L.bce_debug_eval_stages.argtypes = [vp, u32, vp, vp, vp, vp]
     L.bce_debug_ntt.argtypes = [vp, vp, u32, i32]
     _lib = L
@@ -166,8 +168,10 @@ class BinFHEContext:
             pass
 
     # --- KeyGen + BTKeyGen (src/circuit.cpp:90-91) ---
-    def KeyGen(self, seed=0x0FE5EED):
-        self._ck(self._L.bce_keygen(self.h, seed_bytes(seed)))
+    def KeyGen(self, seed=None):
+        """seed=None: keys from OS entropy (the reference's cc.KeyGen()); an explicit seed gives reproducible
+        keys (oracle parity tests, one key set replicated on every rank)."""
+        self._ck(self._L.bce_keygen(self.h, None if seed is None else seed_bytes(seed)))
 
     BTKeyGen = KeyGen
 
@@ -210,8 +214,14 @@ class BinFHEContext:
         self._ck(self._L.bce_lwe_read(self.h, _p(slots), slots.size, _p(out)))
         return out
 
+    def set_encrypt_seed(self, seed):
+        """Deterministic encryption streams (parity tests / identical inputs on every rank); None = back to
+        OS entropy + the context's own counter (the default)."""
+        self._ck(self._L.bce_set_encrypt_seed(self.h, None if seed is None else seed_bytes(seed)))
+
     # --- Encrypt / Decrypt (src/circuit.cpp:506,800) ---
     def Encrypt(self, bits, slots, enc_index_base=0, mode=FRESH):
+        """enc_index_base only matters after set_encrypt_seed(); by default the context numbers its streams itself"""
         bits = np.ascontiguousarray(bits, dtype=np.uint8)
         slots = np.ascontiguousarray(slots, dtype=np.uint32)
         assert bits.size == slots.size
@@ -254,6 +264,11 @@ class BinFHEContext:
     def bytes_per_bootstrap(self):
         return int(self._L.bce_bytes_per_bootstrap(self.h))
 
+    def bytes_per_bootstrap_parts(self):
+        buf = (C.c_uint64 * 3)()
+        self._ck(self._L.bce_bytes_per_bootstrap_parts(self.h, buf))
+        return {"bsk": int(buf[0]), "ksk": int(buf[1]), "ct": int(buf[2])}
+
     # --- staged outputs for parity ---
     def debug_eval_stages(self, descs):
         arr = make_descs(descs)
@@ -278,7 +293,7 @@ class CircuitInfo(C.Structure):
     _fields_ = [("n_gates", C.c_uint32), ("n_input_gates", C.c_uint32), ("n_wires", C.c_uint32),
                 ("n_inputs", C.c_uint32), ("n_input_bits", C.c_uint32 * 2), ("n_output_bits", C.c_uint32),
                 ("n_levels", C.c_uint32), ("n_sublaunches", C.c_uint32), ("n_relevel_steps", C.c_uint32),
-                ("max_frontier", C.c_uint32),
+                ("max_frontier", C.c_uint32), ("slot_stride", C.c_uint32),
                 ("n_bootstraps", C.c_uint64)]
 
 

@@ -153,8 +153,7 @@ Circuit::Circuit(int set, int method) {
     if (rc != BCE_OK) throw std::runtime_error(std::string("GenerateBinFHEContext: ") + bce_last_error(nullptr));
     owns_engine_ = true;
     std::cout << "Generating crypto keys" << std::endl;
-    uint8_t seed[32] = {0xED, 0xE5, 0x0F};
-    rc = bce_keygen(cc, seed);
+    rc = bce_keygen(cc, nullptr);  // cc.KeyGen() + BTKeyGen (src/circuit.cpp:90-91): seed from OS entropy
     if (rc != BCE_OK) {
         std::string m = bce_last_error(cc);
         bce_ctx_destroy(cc);
@@ -888,6 +887,7 @@ bce_circuit_info Circuit::info() const {
     I.n_output_bits = n_output_bits.empty() ? 0 : n_output_bits[0];
     I.n_levels = (uint32_t)levels_.size();
     I.n_relevel_steps = (uint32_t)relevel_plan_.size();
+    I.slot_stride = stride_;
     for (const auto& L : levels_) {
         uint32_t a = 0, b = 0;
         for (int gi : L.gates) {

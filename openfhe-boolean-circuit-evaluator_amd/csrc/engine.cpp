@@ -6,6 +6,7 @@
 // (src/gate.cpp:112,133,172,198-202), the latter batched per ready frontier.
 // There is no CPU compute path here: without a HIP device every call fails loudly.
 #include <hip/hip_runtime_api.h>
+#include <sys/random.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -46,6 +47,23 @@ const ParamRow kParamTable[] = {
 
 struct EventPair { hipEvent_t a, b; int kind; };
 
+// 32 bytes from the operating system's entropy pool (getrandom, then /dev/urandom).  There is no fixed
+// fallback value: a context that cannot get entropy fails to draw keys / encryption randomness.
+bool os_entropy(uint8_t out[32]) {
+    size_t got = 0;
+    while (got < 32) {
+        const ssize_t r = getrandom(out + got, 32 - got, 0);
+        if (r <= 0) break;
+        got += (size_t)r;
+    }
+    if (got == 32) return true;
+    FILE* f = std::fopen("/dev/urandom", "rb");
+    if (!f) return false;
+    const size_t n = std::fread(out, 1, 32, f);
+    std::fclose(f);
+    return n == 32;
+}
+
 }  // namespace
 
 struct bce_ctx {
@@ -71,7 +89,13 @@ struct bce_ctx {
     bool have_keys = false;
     // host secrets
     std::vector<int32_t> s, z;
-    uint8_t seed[32] = {0};
+    uint8_t seed[32] = {0};       // key-generation seed (bce_keygen); zero after bce_import_keys
+    // Encryption randomness is independent of the key seed: drawn from OS entropy when the context is created,
+    // consumed through a per-context counter that only moves forward, so no (a, e) pair is ever reused.
+    // bce_set_encrypt_seed() switches to the deterministic, caller-indexed streams of the parity tests.
+    uint8_t enc_seed[32] = {0};
+    bool enc_seed_ok = false, enc_deterministic = false;
+    uint64_t enc_counter = 0;
     // pool
     u32* d_pool = nullptr;
     u32 pool_slots = 0;
@@ -249,12 +273,13 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         if (hipMalloc(&c->d_tw64, sizeof(ulonglong2) * N) != hipSuccess) { g_create_error = "hipMalloc(twiddles64) failed"; return BCE_ERR_HIP; }
         hipMemcpy(c->d_tw64, tw64.data(), sizeof(ulonglong2) * N, hipMemcpyHostToDevice);
         P.tw64 = c->d_tw64;
-        if (blind_rotate64_lds_bytes(P) > 160 * 1024) { g_create_error = "64-bit path: polynomials do not fit the 160 KiB LDS"; return BCE_ERR_UNSUPPORTED; }
         P.lazy = 1;
         // double-precision formulation (kernels64.hip, namespace wd): exact for Q < 2^39; BCE_FP64=0 keeps the
         // integer kernel (development / parity knob)
         const char* fp = std::getenv("BCE_FP64");
         P.fp64 = (Q < (1ull << 39) && !(fp && fp[0] == '0')) ? 1 : 0;
+        // includes the 16 KiB twiddle mirror of the 8-wave N = 2048 kernel (n <= ~1020 there)
+        if (blind_rotate64_lds_bytes(P) > 160 * 1024) { g_create_error = "64-bit path: polynomials (+ twiddle mirror) do not fit the 160 KiB LDS"; return BCE_ERR_UNSUPPORTED; }
         P.Qd = (double)Q;
         P.invQd = 1.0 / (double)Q;
         P.Ninvd = (double)ninv;
@@ -266,6 +291,7 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         P.tw64d = c->d_tw64d;
     }
     P.pool_stride = n + 1;
+    c->enc_seed_ok = os_entropy(c->enc_seed);
     *out = c.release();
     return BCE_OK;
 }
@@ -620,8 +646,14 @@ int bce_get_params(const bce_ctx* c, uint64_t out[BCE_P_COUNT]) {
 uint64_t bce_bsk_words(const bce_ctx* c) { return c ? rgsw_rows_total(c) * 2 * c->N : 0; }
 uint64_t bce_ksk_words(const bce_ctx* c) { return c ? (u64)c->N * c->baseKS * c->dKS * (c->n + 1) : 0; }
 
-int bce_keygen(bce_ctx* c, const uint8_t seed[32]) {
-    if (!c || !seed) return BCE_ERR_ARG;
+int bce_keygen(bce_ctx* c, const uint8_t seed_in[32]) {
+    if (!c) return BCE_ERR_ARG;
+    uint8_t fresh[32];
+    const uint8_t* seed = seed_in;
+    if (!seed) {  // cc.KeyGen() of the reference: keys from the system's entropy, never from a constant
+        if (!os_entropy(fresh)) return c->fail(BCE_ERR_STATE, "bce_keygen: no entropy source (getrandom and /dev/urandom failed)");
+        seed = fresh;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = alloc_keys(c);
     if (rc) return rc;
@@ -725,6 +757,7 @@ int bce_export_bsk(bce_ctx* c, uint64_t* bsk) {
     const u64 chunk_polys = std::max<u64>(1, ((u64)256 << 20) / ((u64)c->N * c->wbytes));
     void* d_tmp = nullptr;
     HIP_TRY(c, hipMalloc(&d_tmp, chunk_polys * c->N * c->wbytes));
+    struct Free { void* p; ~Free() { hipFree(p); } } free_tmp{d_tmp};  // released on every return path
     std::vector<u32> tmp32;
     for (u64 p0 = 0; p0 < words / c->N; p0 += chunk_polys) {
         const u64 cnt = std::min(chunk_polys, words / c->N - p0), w = cnt * c->N;
@@ -742,7 +775,6 @@ int bce_export_bsk(bce_ctx* c, uint64_t* bsk) {
             for (u64 i = 0; i < w; ++i) bsk[p0 * c->N + i] = tmp32[i];
         }
     }
-    hipFree(d_tmp);
     return BCE_OK;
 }
 
@@ -844,8 +876,14 @@ int bce_encrypt_bits(bce_ctx* c, const uint8_t* bits, const uint32_t* slots, uin
     const size_t W = n + 1;
     const GaussSampler gauss(3.19);
     std::vector<u64> cts((size_t)count * W);
+    if (!c->enc_deterministic) {
+        // default: the caller's index is ignored; the context's own counter names the stream and never repeats
+        if (!c->enc_seed_ok) return c->fail(BCE_ERR_STATE, "no entropy source for encryption randomness (getrandom and /dev/urandom failed)");
+        enc_index_base = c->enc_counter;
+        c->enc_counter += count;
+    }
     for (u32 i = 0; i < count; ++i) {
-        ChaChaStream st(c->seed, kDomENC, enc_index_base + i);
+        ChaChaStream st(c->enc_seed, kDomENC, enc_index_base + i);
         u64* ct = &cts[(size_t)i * W];
         u128 acc = 0;
         for (u32 k = 0; k < n; ++k) {
@@ -861,6 +899,21 @@ int bce_encrypt_bits(bce_ctx* c, const uint8_t* bits, const uint32_t* slots, uin
         std::vector<bce_gate_desc> d(count);
         for (u32 i = 0; i < count; ++i) d[i] = bce_gate_desc{BCE_OP_REFRESH, slots[i], slots[i], slots[i], 0, 0};
         return bce_eval_gates(c, count, d.data());
+    }
+    return BCE_OK;
+}
+
+int bce_set_encrypt_seed(bce_ctx* c, const uint8_t seed[32]) {
+    if (!c) return BCE_ERR_ARG;
+    if (seed) {
+        std::memcpy(c->enc_seed, seed, 32);
+        c->enc_seed_ok = true;
+        c->enc_deterministic = true;
+    } else {
+        c->enc_deterministic = false;
+        c->enc_counter = 0;
+        c->enc_seed_ok = os_entropy(c->enc_seed);
+        if (!c->enc_seed_ok) return c->fail(BCE_ERR_STATE, "no entropy source (getrandom and /dev/urandom failed)");
     }
     return BCE_OK;
 }
@@ -916,6 +969,15 @@ int bce_timing_get(bce_ctx* c, bce_timing* out) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_timing(c);
     *out = c->timing;
+    return BCE_OK;
+}
+
+int bce_bytes_per_bootstrap_parts(const bce_ctx* c, uint64_t out[3]) {
+    if (!c || !out) return BCE_ERR_ARG;
+    const double rgsws = c->method == BCE_AP ? (double)c->n * c->dR * (c->baseR - 1) / c->baseR : 2.0 * c->n;
+    out[0] = (u64)((double)c->wbytes * rgsws * (2 * c->dG) * 2 * c->N);
+    out[1] = (c->P.ksk_u16 ? 2ull : 4ull) * c->N * c->dKS * (c->n + 1);
+    out[2] = 4ull * 3 * (c->n + 1);
     return BCE_OK;
 }
 

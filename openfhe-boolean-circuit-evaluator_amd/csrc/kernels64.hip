@@ -1108,7 +1108,9 @@ hipError_t launch_words_u64_f64(u64* words, size_t count, int to_double, hipStre
 
 size_t blind_rotate64_lds_bytes(const DevParams& P) {
     const size_t N = P.N, NP = N + (N >> 6) * 4, R = 2 * P.dG;
-    return (2 + R) * NP * sizeof(u64) + ((P.n + 1 + 3) & ~3u) * sizeof(u32);
+    // the 8-wave double-precision kernel (N = 2048, 3 gadget digits) also mirrors the first 1024 twiddle entries
+    const size_t mirror = (P.fp64 && P.logN == 11 && P.dG == 3) ? 1024 * sizeof(double2) : 0;
+    return (2 + R) * NP * sizeof(u64) + ((P.n + 1 + 3) & ~3u) * sizeof(u32) + mirror;
 }
 
 hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
@@ -1137,8 +1139,7 @@ hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32
         kern = ap ? w64::k_blind_rotate64<9, 4, true> : w64::k_blind_rotate64<9, 4, false>;
     }
     if (!kern) return hipErrorInvalidValue;
-    // the 8-wave double-precision kernel also mirrors the first 1024 twiddle entries (16 KiB) in LDS
-    const size_t lds = blind_rotate64_lds_bytes(P) + ((P.fp64 && threads == 512) ? 1024 * sizeof(double2) : 0);
+    const size_t lds = blind_rotate64_lds_bytes(P);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(n_desc * instances), dim3(threads), lds, s, P, d, n_desc, slot_stride, acc_out);

@@ -1,0 +1,55 @@
+"""bench.py starts its own ranks: `python3 bench.py --gpus N` (how the driver invokes it) must spawn N child
+processes, rendezvous them on 127.0.0.1 and fail loudly -- not hang, not silently fall back -- when something is
+missing.  The CPU test runs without a GPU (the ranks meet over gloo, then every rank reports that the engine
+needs a GPU and the parent exits non-zero); the GPU test rehearses the whole N = 2 path on the one GPU of the
+test box (both ranks on device 0, gloo carrying the collectives), including the secondary gate-sharded run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _run(args, timeout):
+    env = dict(os.environ, BCE_BENCH_SINGLE_DEVICE="1", BCE_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus2_spawns_ranks_and_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu-marked rehearsal below")
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], timeout=300)
+    assert p.returncode != 0
+    assert "rank 0/2 rendezvous ok" in p.stderr and "rank 1/2 rendezvous ok" in p.stderr, p.stderr[-2000:]
+    assert p.stderr.count("needs a GPU") == 2, p.stderr[-2000:]
+    assert "ranks failed" in p.stderr and not any(l.startswith("{") for l in p.stdout.splitlines())
+
+
+def test_bench_rejects_mismatched_world_size():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0 and "does not match" in p.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_rehearsal_on_one_gpu():
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--circuit", "adder_32bit.txt", "--instances", "4",
+              "--gates-steps", "1"], timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, p.stdout
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["outputs_verified"] is True
+    assert d["config"]["bootstraps_per_step"] == 2 * 4 * 310          # adder_32bit: 310 bootstraps, K = 4 per rank
+    g = d["shard_gates"]
+    assert g["outputs_verified"] is True and g["scaling"] == "strong"
+    assert g["exchanges_per_step"] > 0 and g["exchanged_cts_per_step"] > 0
+    assert "roofline" in d and "cpu_baseline" not in d               # the CPU baseline is an N = 1 leg

@@ -26,6 +26,7 @@ def _worker(rank, world, port, shard_mode, K, q):
         import kat
         cc = bce.BinFHEContext(bce.TOY, bce.GINX, device=0)
         cc.KeyGen(0x0FE5EED)                       # same seed on every rank = replicated keys
+        cc.set_encrypt_seed(0x0FE5EED)             # and identical input ciphertexts on every rank (gate sharding needs them)
         c = bce.Circuit(cc)
         c.ReadBristol(os.path.join(kat.CIRCUITS, "adder_32bit.txt"))
         c.setInstances(K)
