@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libbce_amd.so")
 OBJ = os.path.join(HERE, "_obj")
 
-SOURCES = ["kernels.hip", "kernels64.hip", "engine.cpp", "bristol.cpp", "circuit.cpp", "circuit_capi.cpp"]
+SOURCES = ["kernels.hip", "kernels64.hip", "keygen.hip", "engine.cpp", "bristol.cpp", "circuit.cpp", "circuit_capi.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-Wall",
          "-Wno-unused-result", "-Wno-unused-value"]
 FLAGS += os.environ.get("BCE_EXTRA_FLAGS", "").split()  # development builds only (e.g. -DBCE_PHASE_PROF)

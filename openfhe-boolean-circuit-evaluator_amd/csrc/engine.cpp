@@ -15,13 +15,13 @@
 #include <cstring>
 #include <memory>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/bce_circuit.h"
 #include "../../include/bce_gpu.h"
 #include "host_math.hpp"
 #include "kernels.hpp"
+#include "keygen.hpp"
 #include "prng.hpp"
 
 using namespace bce;
@@ -340,18 +340,6 @@ int upload_ksk(bce_ctx* c, const u32* ksk) {
     return BCE_OK;
 }
 
-template <typename F>
-void parallel_for(size_t count, F fn) {
-    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    if (count < 2 * nt) nt = 1;
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; ++t)
-        th.emplace_back([=]() {
-            for (size_t i = t; i < count; i += nt) fn(i);
-        });
-    for (auto& x : th) x.join();
-}
-
 int ensure_acc(bce_ctx* c, size_t boots) {
     if (boots <= c->acc_cap) return BCE_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -424,87 +412,69 @@ int dev_ntt(bce_ctx* c, void* polys, u64 count, int inverse) {
     return BCE_OK;
 }
 
+// device copies of what the key samplers read (keygen.hip): secrets, Gaussian CDF table, parameters
+struct KeygenDev {
+    int32_t *s = nullptr, *z = nullptr;
+    u64* cdf = nullptr;
+    void *ta = nullptr, *zq = nullptr;
+    ~KeygenDev() { hipFree(s); hipFree(z); hipFree(cdf); hipFree(ta); hipFree(zq); }
+};
+
+int keygen_params(bce_ctx* c, const GaussSampler& gauss, KeygenDev& D, KeygenParams& kp) {
+    HIP_TRY(c, hipMalloc(&D.s, c->n * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc(&D.z, c->N * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc(&D.cdf, 81 * sizeof(u64)));
+    HIP_TRY(c, hipMemcpy(D.s, c->s.data(), c->n * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(D.z, c->z.data(), c->N * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(D.cdf, gauss.table(), 81 * sizeof(u64), hipMemcpyHostToDevice));
+    std::memcpy(kp.seed, c->seed, 32);
+    kp.n = c->n; kp.N = c->N; kp.Q = c->Q; kp.q = c->q; kp.qKS = c->qKS;
+    kp.qbits = bit_length(c->Q - 1); kp.ksbits = bit_length(c->qKS - 1);
+    kp.R = 2 * c->dG; kp.ap = c->method == BCE_AP ? 1 : 0; kp.baseR = c->baseR; kp.dR = c->dR;
+    kp.baseKS = c->baseKS; kp.dKS = c->dKS; kp.ksk_stride = c->P.ksk_stride;
+    { u64 v = 1; for (u32 i = 0; i < 4; ++i) { kp.gpow[i] = v; v = mul_mod(v, c->baseG, c->Q); } }
+    kp.s = D.s; kp.z = D.z; kp.cdf = D.cdf;
+    return BCE_OK;
+}
+
 // Bootstrapping key.  GINX: ek[i][0] = RGSW(s_i == 1), ek[i][1] = RGSW(s_i == -1)
 // (rgsw-acc-cggi.cpp KeyGenAcc).  AP: ek[i][v][k] = RGSW(X^{s_i * v * baseR^k * 2N/q}), v >= 1
 // (rgsw-acc-dm.cpp KeyGenAcc; the v = 0 slots stay zero and are never read).
-// The host draws (a, e) per row and adds the gadget; the device does the NTTs and a*z.
-// Rows are produced in chunks so that host staging stays below ~0.75 GB whatever the key size
-// (STD192/AP: 12.9 GB of key).
-template <typename W>
-int keygen_bsk(bce_ctx* c, const GaussSampler& gauss) {
+// Everything happens on the device: rows (a, e + gadget) are sampled in place (keygen.hip), transformed, and
+// b += NTT(a) * NTT(z).  Rows are produced in chunks whose scratch (the masks once more) stays below 1 GiB
+// whatever the key size (STD192/AP: 12.9 GB of key).
+int keygen_bsk(bce_ctx* c, const KeygenParams& kp, KeygenDev& D) {
     const u32 N = c->N, R = 2 * c->dG;
     const u64 Q = c->Q;
+    const size_t wb = c->wbytes;
     const u64 rows = rgsw_rows_total(c);
-    const u64 chunk = std::max<u64>(R, std::min<u64>(rows, ((u64)256 << 20) / ((u64)N * sizeof(W))) / R * R);
-    std::vector<W> bsk(chunk * 2 * N), ta(chunk * N);
-    std::vector<u64> gpow(c->dG);
-    { u64 v = 1; for (u32 i = 0; i < c->dG; ++i) { gpow[i] = v; v = mul_mod(v, c->baseG, Q); } }
-    std::vector<W> zq(N);
-    for (u32 k = 0; k < N; ++k) zq[k] = (W)lift_signed(c->z[k], Q);
-    W *d_ta = nullptr, *d_z = nullptr;
-    HIP_TRY(c, hipMalloc(&d_ta, chunk * N * sizeof(W)));
-    HIP_TRY(c, hipMalloc(&d_z, N * sizeof(W)));
-    HIP_TRY(c, hipMemcpy(d_z, zq.data(), N * sizeof(W), hipMemcpyHostToDevice));
-    int rc = dev_ntt(c, d_z, 1, 0);
+    const u64 chunk = std::max<u64>(R, std::min<u64>(rows, ((u64)1 << 30) / ((u64)N * wb)) / R * R);
+    HIP_TRY(c, hipMalloc(&D.ta, chunk * N * wb));
+    HIP_TRY(c, hipMalloc(&D.zq, N * wb));
+    {
+        std::vector<u64> zq(N);
+        for (u32 k = 0; k < N; ++k) zq[k] = lift_signed(c->z[k], Q);
+        if (c->is64) {
+            HIP_TRY(c, hipMemcpy(D.zq, zq.data(), N * 8, hipMemcpyHostToDevice));
+        } else {
+            std::vector<u32> z32(zq.begin(), zq.end());
+            HIP_TRY(c, hipMemcpy(D.zq, z32.data(), N * 4, hipMemcpyHostToDevice));
+        }
+    }
+    int rc = dev_ntt(c, D.zq, 1, 0);
     if (rc) return rc;
-    const u64* gp = gpow.data();
-    const int32_t* s = c->s.data();
-    const uint8_t* sd = c->seed;
-    const bool ap = c->method == BCE_AP;
-    const u32 BR = c->baseR, DR = c->dR;
-    const int64_t qq = (int64_t)c->q;
-    W* dev = static_cast<W*>(c->d_bsk);
+    char* dev = static_cast<char*>(c->d_bsk);
     for (u64 r0 = 0; r0 < rows; r0 += chunk) {
         const u64 cnt = std::min(chunk, rows - r0);
-        std::fill(bsk.begin(), bsk.begin() + cnt * 2 * N, (W)0);
-        std::fill(ta.begin(), ta.begin() + cnt * N, (W)0);
-        W* bp = bsk.data();
-        W* tp = ta.data();
-        parallel_for(cnt, [=, &gauss](size_t local) {
-            const u64 rowid = r0 + local;
-            const u32 r = (u32)(rowid % R);
-            const u64 ek = rowid / R;
-            bool one;
-            u32 mm = 0;
-            bool negate = false;
-            if (!ap) {
-                const u32 i = (u32)(ek / 2), key = (u32)(ek % 2);   // ek = i*2 + key
-                one = key == 0 ? (s[i] == 1) : (s[i] == -1);
-            } else {
-                const u32 k = (u32)(ek % DR), v = (u32)((ek / DR) % BR), i = (u32)(ek / DR / BR);
-                if (v == 0) return;
-                int64_t pw = 1;
-                for (u32 t = 0; t < k; ++t) pw *= BR;
-                const int64_t m = (int64_t)s[i] * (int64_t)v * pw;
-                int64_t e = (((m % qq) + qq) % qq) * (int64_t)(2 * N / qq);
-                if (e >= (int64_t)N) { e -= N; negate = true; }
-                mm = (u32)e;
-                one = true;
-            }
-            ChaChaStream st(sd, kDomBSK, rowid);
-            W* a = bp + (local * 2 + 0) * N;
-            W* b = bp + (local * 2 + 1) * N;
-            W* t = tp + local * N;
-            for (u32 k = 0; k < N; ++k) t[k] = a[k] = (W)draw_uniform(st, Q);
-            for (u32 k = 0; k < N; ++k) b[k] = (W)lift_signed(gauss.draw(st), Q);
-            if (one) {
-                W* tgt = (r & 1) ? b : a;        // row 2j: column 0, row 2j+1: column 1
-                const u64 g = gp[r >> 1];
-                tgt[mm] = (W)(((u64)tgt[mm] + (negate ? Q - g : g)) % Q);
-            }
-        });
-        W* dst = dev + r0 * 2 * N;
-        HIP_TRY(c, hipMemcpy(dst, bsk.data(), cnt * 2 * N * sizeof(W), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(d_ta, ta.data(), cnt * N * sizeof(W), hipMemcpyHostToDevice));
+        char* dst = dev + r0 * 2 * N * wb;
+        HIP_TRY(c, launch_gen_bsk_rows(kp, r0, (u32)cnt, dst, D.ta, c->is64 ? 1 : 0, c->stream));
         if ((rc = dev_ntt(c, dst, cnt * 2, 0))) return rc;
-        if ((rc = dev_ntt(c, d_ta, cnt, 0))) return rc;
+        if ((rc = dev_ntt(c, D.ta, cnt, 0))) return rc;
         // b-column (odd polys) += NTT(a) * NTT(z)
-        if constexpr (sizeof(W) == 8) HIP_TRY(c, launch_pointwise_mac64(c->P, (u64*)dst + N, (const u64*)d_ta, (const u64*)d_z, (u32)cnt, 2, c->stream));
-        else HIP_TRY(c, launch_pointwise_mac(c->P, (u32*)dst + N, (const u32*)d_ta, (const u32*)d_z, (u32)cnt, 2, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->is64) HIP_TRY(c, launch_pointwise_mac64(c->P, (u64*)dst + N, (const u64*)D.ta, (const u64*)D.zq, (u32)cnt, 2, c->stream));
+        else HIP_TRY(c, launch_pointwise_mac(c->P, (u32*)dst + N, (const u32*)D.ta, (const u32*)D.zq, (u32)cnt, 2, c->stream));
     }
-    hipFree(d_ta);
-    hipFree(d_z);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return BCE_OK;
 }
 
@@ -659,48 +629,23 @@ int bce_keygen(bce_ctx* c, const uint8_t seed_in[32]) {
     if (rc) return rc;
     std::memcpy(c->seed, seed, 32);
     const u32 n = c->n, N = c->N;
-    const u64 qKS = c->qKS;
     const GaussSampler gauss(3.19);
     c->s.resize(n);
     c->z.resize(N);
     { ChaChaStream st(seed, kDomSK, 0); for (u32 i = 0; i < n; ++i) c->s[i] = draw_ternary(st); }
     { ChaChaStream st(seed, kDomZ, 0); for (u32 i = 0; i < N; ++i) c->z[i] = draw_ternary(st); }
 
-    // LWE key-switching key: K[i][v][j] = LWE_s(z_i * v * baseKS^j) mod qKS
+    KeygenDev D;
+    KeygenParams kp{};
+    if ((rc = keygen_params(c, gauss, D, kp))) return rc;
+    // LWE key-switching key: K[i][v][j] = LWE_s(z_i * v * baseKS^j) mod qKS, sampled on the device straight into
+    // the padded row layout the tail kernel gathers from
     {
-        const u32 B = c->baseKS, D = c->dKS;
-        const size_t W = n + 1;
-        std::vector<u32> ksk((size_t)N * B * D * W);
-        std::vector<u64> pw(D);
-        { u64 v = 1; for (u32 j = 0; j < D; ++j) { pw[j] = v; v *= B; } }
-        const int32_t* s = c->s.data();
-        const int32_t* z = c->z.data();
-        u32* kp = ksk.data();
-        const u64* pwp = pw.data();
-        const uint8_t* sd = c->seed;
-        parallel_for(N, [=, &gauss](size_t i) {
-            const u64 zi = lift_signed(z[i], qKS);
-            for (u32 v = 0; v < B; ++v)
-                for (u32 j = 0; j < D; ++j) {
-                    const u64 idx = ((u64)i * B + v) * D + j;
-                    ChaChaStream st(sd, kDomKSK, idx);
-                    u32* row = kp + idx * W;
-                    u128 acc = 0;
-                    for (u32 k = 0; k < n; ++k) {
-                        u64 a = draw_uniform(st, qKS);
-                        row[k] = (u32)a;
-                        acc += (u128)a * lift_signed(s[k], qKS);
-                    }
-                    u64 e = lift_signed(gauss.draw(st), qKS);
-                    u64 msg = (u64)((u128)zi * (u64)((u128)v * pwp[j] % qKS) % qKS);
-                    row[n] = (u32)((acc + e + msg) % qKS);
-                }
-        });
-        rc = upload_ksk(c, ksk.data());
-        if (rc) return rc;
+        const u64 rows = (u64)N * c->baseKS * c->dKS;
+        HIP_TRY(c, hipMemsetAsync(c->d_ksk, 0, rows * c->P.ksk_stride * (c->P.ksk_u16 ? 2 : 4), c->stream));
+        HIP_TRY(c, launch_gen_ksk_rows(kp, rows, c->d_ksk, c->P.ksk_u16 ? 1 : 0, c->stream));
     }
-
-    rc = c->is64 ? keygen_bsk<u64>(c, gauss) : keygen_bsk<u32>(c, gauss);
+    rc = keygen_bsk(c, kp, D);
     if (!rc) rc = bsk_words_to_kernel_layout(c);
     if (rc) return rc;
     c->have_keys = true;

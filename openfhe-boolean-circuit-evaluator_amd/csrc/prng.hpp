@@ -115,6 +115,7 @@ public:
         }
         return lo - kTail;
     }
+    const uint64_t* table() const { return cdf_; }  // 2 * kTail + 1 entries (device copy for keygen.hip)
 
 private:
     uint64_t cdf_[2 * kTail + 1];
