@@ -28,8 +28,8 @@ typedef struct bce_circuit_info {
     uint32_t n_input_gates;  /* LOADs                                                    */
     uint32_t n_wires;        /* registers                                                */
     uint32_t n_inputs;       /* number of input buses referenced (In1, In2)              */
-    uint32_t n_input_bits[2];
-    uint32_t n_output_bits;  /* max STORE index + 1 (single output bus)                  */
+    uint32_t n_input_bits[2]; /* the first two buses; all of them: bce_circuit_get_buses()   */
+    uint32_t n_output_bits;  /* max STORE index + 1 = all output values concatenated      */
     uint32_t n_levels;       /* Clock() rounds = ASAP levels incl. NOT and OUTPUT levels */
     uint32_t n_sublaunches;  /* dependent bce_eval_gates launches per evaluation          */
     uint32_t n_relevel_steps;/* dependent launches of the opt-in re-levelled schedule     */
@@ -98,8 +98,13 @@ int bce_circuit_set_input(bce_circuit*, uint32_t instance, const uint32_t* width
                           const uint8_t* bits);
 /* Circuit::Clock, src/circuit.cpp:532-573 */
 int bce_circuit_clock(bce_circuit*);
-/* Outputs[0][bit] of one instance after Clock() */
+/* Outputs of one instance after Clock(): the bits of all output values, concatenated in header order
+ * (n_output_bits in total; the reference has a single output bus, Outputs[0][bit]) */
 int bce_circuit_get_output(const bce_circuit*, uint32_t instance, uint8_t* bits);
+/* widths of every input and output value (Bristol Fashion headers may name any number of either;
+ * src/analyze.cpp:129-158 hard-codes 2 / 1).  Arrays may be NULL to query the counts only. */
+int bce_circuit_get_buses(const bce_circuit*, uint32_t* n_in, uint32_t* in_widths, uint32_t in_cap, uint32_t* n_out,
+                          uint32_t* out_widths, uint32_t out_cap);
 /* dumpGateCount counters: input, output, not, and, or, xor (src/circuit.cpp:866-873) */
 int bce_circuit_get_counts(const bce_circuit*, uint32_t out[6]);
 int bce_circuit_get_stats(const bce_circuit*, bce_circuit_stats* out);

@@ -310,7 +310,7 @@ CIRCUIT_SYMBOLS = [
     "bce_circuit_read_bristol", "bce_circuit_get_info", "bce_circuit_reset", "bce_circuit_rearm", "bce_circuit_set_plaintext",
     "bce_circuit_set_encrypted", "bce_circuit_set_verify", "bce_circuit_get_flags", "bce_circuit_set_batched",
     "bce_circuit_set_encrypt_mode", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
-    "bce_circuit_get_output", "bce_circuit_get_counts", "bce_circuit_get_stats", "bce_circuit_dump",
+    "bce_circuit_get_output", "bce_circuit_get_buses", "bce_circuit_get_counts", "bce_circuit_get_stats", "bce_circuit_dump",
     "bce_circuit_set_exchange", "bce_circuit_exchange_capacity", "bce_assemble_bristol", "bce_pool_gather",
     "bce_pool_scatter",
 ]
@@ -340,6 +340,7 @@ def _bind_circuit():
     L.bce_circuit_set_instances.argtypes = [vp, u32]
     L.bce_circuit_set_input.argtypes = [vp, u32, vp, u32, vp]
     L.bce_circuit_get_output.argtypes = [vp, u32, vp]
+    L.bce_circuit_get_buses.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), u32, C.POINTER(u32), C.POINTER(u32), u32]
     L.bce_circuit_get_counts.argtypes = [vp, C.POINTER(u32 * 6)]
     L.bce_circuit_get_stats.argtypes = [vp, C.POINTER(CircuitStats)]
     L.bce_circuit_set_exchange.argtypes = [vp, u32, u32, i32, ALLGATHER_FN, vp, vp, vp, vp, vp, u64]
@@ -417,8 +418,20 @@ class Circuit:
         i = CircuitInfo()
         self._ck(self._L.bce_circuit_get_info(self.h, C.byref(i)))
         d = {k: getattr(i, k) for k, _ in CircuitInfo._fields_ if k != "n_input_bits"}
-        d["n_input_bits"] = [int(i.n_input_bits[0]), int(i.n_input_bits[1])]
+        ins, outs = self.buses()
+        d["n_input_bits"] = ins + [0] * (2 - len(ins))    # at least two entries, as the reference's two-input header
+        d["output_buses"] = outs
         return d
+
+    def buses(self):
+        """(input bus widths, output bus widths) -- Bristol Fashion headers may name any number of either"""
+        ni, no = C.c_uint32(), C.c_uint32()
+        iw, ow = (C.c_uint32 * 64)(), (C.c_uint32 * 64)()
+        self._ck(self._L.bce_circuit_get_buses(self.h, C.byref(ni), iw, 64, C.byref(no), ow, 64))
+        ins = [int(iw[k]) for k in range(min(64, ni.value))]
+        while len(ins) > 1 and ins[-1] == 0:
+            ins.pop()
+        return ins, [int(ow[k]) for k in range(min(64, no.value))]
 
     def Reset(self):
         self._ck(self._L.bce_circuit_reset(self.h))
@@ -479,10 +492,19 @@ class Circuit:
         return self.Outputs(instance)
 
     def Outputs(self, instance=0):
-        n = self.info()["n_output_bits"]
+        """Outputs[k][bit] like the reference (one list per output value; the reference's circuits have one)"""
+        i = CircuitInfo()
+        self._ck(self._L.bce_circuit_get_info(self.h, C.byref(i)))
+        n = i.n_output_bits
         out = np.zeros(max(n, 1), dtype=np.uint8)
         self._ck(self._L.bce_circuit_get_output(self.h, int(instance), _p(out)))
-        return [[int(v) for v in out[:n]]]
+        bits = [int(v) for v in out[:n]]
+        widths = self.buses()[1] or [n]
+        res, pos = [], 0
+        for w in widths:
+            res.append(bits[pos:pos + w])
+            pos += w
+        return res
 
     def counts(self):
         c = (C.c_uint32 * 6)()

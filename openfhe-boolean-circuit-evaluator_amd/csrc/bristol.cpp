@@ -31,31 +31,48 @@ Analysis analyze_bristol(const std::string& in_fname, bool gen_fan_flag, bool ne
         throw std::runtime_error("analyze_bristol: bad first header line in " + in_fname);
     v.n_inputs = 2;
     if (new_flag) {
-        // "<n_inputs> <w1> [<w2> ...]" / "<n_outputs> <w1> ..." / blank  (src/analyze.cpp:129-158)
-        unsigned n_out = 0;
+        // "<n_inputs> <w1> [<w2> ...]" / "<n_outputs> <w1> ..." / blank  (src/analyze.cpp:129-158 reads two input
+        // widths and one output width; Bristol Fashion files may carry any number of either)
         if (!next_line(f, line)) throw std::runtime_error("analyze_bristol: truncated header");
         {
             std::istringstream s(line);
-            s >> v.n_inputs >> v.n_in1_bits;
-            if (!(s >> v.n_in2_bits)) v.n_in2_bits = 0;
+            unsigned w = 0;
+            if (!(s >> v.n_inputs) || v.n_inputs < 1) throw std::runtime_error("analyze_bristol: bad input header line in " + in_fname);
+            for (unsigned k = 0; k < v.n_inputs; ++k) {
+                if (!(s >> w)) throw std::runtime_error("analyze_bristol: input header names " + std::to_string(v.n_inputs) + " values but lists fewer widths");
+                v.in_bits.push_back(w);
+            }
         }
         if (!next_line(f, line)) throw std::runtime_error("analyze_bristol: truncated header");
         {
-            // "<n_outputs> <w1> [<w2> ...]": several outputs are concatenated on the single output bus the
-            // driver has (outputs are the last sum(w) wires, first output first)
+            // outputs are the last sum(w) wires, first output first
             std::istringstream so(line);
-            so >> n_out;
-            v.n_out1_bits = 0;
-            for (unsigned k = 0, w = 0; k < n_out && (so >> w); ++k) v.n_out1_bits += w;
+            unsigned n_out = 0, w = 0;
+            if (!(so >> n_out) || n_out < 1) throw std::runtime_error("analyze_bristol: bad output header line in " + in_fname);
+            for (unsigned k = 0; k < n_out; ++k) {
+                if (!(so >> w)) throw std::runtime_error("analyze_bristol: output header lists fewer widths than values");
+                v.out_bits.push_back(w);
+            }
         }
-        if (v.n_inputs > 2 || n_out < 1)
-            throw std::runtime_error("analyze_bristol: only <=2 input buses are supported");
         next_line(f, line);
     } else {
         // "<n_in1> <n_in2> <n_out>" / blank  (src/analyze.cpp:160-179)
-        if (!next_line(f, line) || !(std::istringstream(line) >> v.n_in1_bits >> v.n_in2_bits >> v.n_out1_bits))
+        unsigned a = 0, b = 0, o = 0;
+        if (!next_line(f, line) || !(std::istringstream(line) >> a >> b >> o))
             throw std::runtime_error("analyze_bristol: bad second header line in " + in_fname);
+        v.in_bits = {a, b};
+        v.out_bits = {o};
         next_line(f, line);
+    }
+    v.n_in1_bits = v.in_bits.empty() ? 0 : v.in_bits[0];
+    v.n_in2_bits = v.in_bits.size() > 1 ? v.in_bits[1] : 0;
+    v.n_out1_bits = 0;
+    for (unsigned w : v.out_bits) v.n_out1_bits += w;
+    {
+        uint64_t tot_in = 0;
+        for (unsigned w : v.in_bits) tot_in += w;
+        if (tot_in > n_var || v.n_out1_bits > n_var)
+            throw std::runtime_error("analyze_bristol: header widths exceed the wire count");
     }
     v.n_tot = n_var;
     fn.n_tot = n_func;
@@ -65,9 +82,9 @@ Analysis analyze_bristol(const std::string& in_fname, bool gen_fan_flag, bool ne
     v.life.assign(n_var, 0);
     v.fan_in.assign(n_var, 0);
     v.fan_out.assign(n_var, 0);
-    fn.call_list.resize(n_func);
-    fn.in_list.resize(n_func);
-    fn.out_list.resize(n_func);
+    fn.call_list.reserve(n_func);
+    fn.in_list.reserve(n_func);
+    fn.out_list.reserve(n_func);
 
     for (unsigned ix = 0; ix < n_func; ++ix) {
         do {
@@ -76,32 +93,57 @@ Analysis analyze_bristol(const std::string& in_fname, bool gen_fan_flag, bool ne
         std::istringstream s(line);
         unsigned nin = 0, nout = 0;
         s >> nin >> nout;
-        auto& il = fn.in_list[ix];
-        auto& ol = fn.out_list[ix];
-        il.resize(nin);
-        ol.resize(nout);
+        std::vector<unsigned> il(nin), ol(nout);
         for (auto& w : il) s >> w;
         for (auto& w : ol) s >> w;
         std::string op;
         s >> op;
         if (!s) throw std::runtime_error("analyze_bristol: bad gate line " + std::to_string(ix));
         for (auto& ch : op) ch = (char)std::toupper((unsigned char)ch);
-        for (unsigned w : il) if (w >= n_var) throw std::runtime_error("analyze_bristol: wire index out of range");
+        const bool is_eq = op == "EQ";   // "1 1 <0|1> <out> EQ": the input field is a literal, not a wire
+        if (!is_eq) for (unsigned w : il) if (w >= n_var) throw std::runtime_error("analyze_bristol: wire index out of range");
         for (unsigned w : ol) if (w >= n_var) throw std::runtime_error("analyze_bristol: wire index out of range");
-        if (op == "XOR") { ++fn.n_xor; fn.call_list[ix] = "XOR"; }
-        else if (op == "AND") { ++fn.n_and; fn.call_list[ix] = "AND"; }
-        else if (op == "INV" || op == "NOT") { ++fn.n_not; fn.call_list[ix] = "NOT"; }
-        else if (op == "EQW") { ++fn.n_eqw; fn.call_list[ix] = "EQW"; }
-        else if (op == "EQ") throw std::runtime_error("analyze_bristol: cannot parse EQ");   // src/analyze.cpp:273-277
-        else throw std::runtime_error("analyze_bristol: bad parse of function on line " + std::to_string(ix));
         // water marks, with the reference's "0 means unset" convention (src/analyze.cpp:288-301)
         auto touch = [&](unsigned w) {
             if (v.low_water[w] == 0) v.low_water[w] = ix;
             v.high_water[w] = ix;
         };
-        for (unsigned w : il) { touch(w); if (gen_fan_flag) ++v.fan_out[w]; }
-        for (unsigned w : ol) { touch(w); if (gen_fan_flag) ++v.fan_in[w]; }
+        auto add = [&](const char* name, std::vector<unsigned> ins, std::vector<unsigned> outs, bool wires) {
+            if (wires) for (unsigned w : ins) { touch(w); if (gen_fan_flag) ++v.fan_out[w]; }
+            for (unsigned w : outs) { touch(w); if (gen_fan_flag) ++v.fan_in[w]; }
+            fn.call_list.emplace_back(name);
+            fn.in_list.push_back(std::move(ins));
+            fn.out_list.push_back(std::move(outs));
+        };
+        if (op == "XOR" || op == "AND") {
+            if (nin != 2 || nout != 1) throw std::runtime_error("analyze_bristol: " + op + " needs 2 inputs and 1 output (line " + std::to_string(ix) + ")");
+            ++(op == "XOR" ? fn.n_xor : fn.n_and);
+            add(op.c_str(), il, ol, true);
+        } else if (op == "INV" || op == "NOT") {
+            if (nin != 1 || nout != 1) throw std::runtime_error("analyze_bristol: INV needs 1 input and 1 output (line " + std::to_string(ix) + ")");
+            ++fn.n_not;
+            add("NOT", il, ol, true);
+        } else if (op == "EQW") {
+            if (nin != 1 || nout != 1) throw std::runtime_error("analyze_bristol: EQW needs 1 input and 1 output (line " + std::to_string(ix) + ")");
+            ++fn.n_eqw;
+            add("EQW", il, ol, true);
+        } else if (is_eq) {
+            // constant assignment (the reference gives up here: "Cannot parse EQ!! yet failing", src/analyze.cpp:273-277)
+            if (nin != 1 || nout != 1 || il[0] > 1) throw std::runtime_error("analyze_bristol: EQ takes the literal 0 or 1 and one output wire (line " + std::to_string(ix) + ")");
+            ++fn.n_eq;
+            add(" EQ", il, ol, false);
+        } else if (op == "MAND") {
+            // multiple AND: out[k] = in[k] AND in[m + k]; expanded into m two-input ANDs
+            if (nout == 0 || nin != 2 * nout) throw std::runtime_error("analyze_bristol: MAND needs 2m inputs and m outputs (line " + std::to_string(ix) + ")");
+            for (unsigned k = 0; k < nout; ++k) {
+                ++fn.n_and;
+                add("AND", {il[k], il[nout + k]}, {ol[k]}, true);
+            }
+        } else {
+            throw std::runtime_error("analyze_bristol: bad parse of function on line " + std::to_string(ix));
+        }
     }
+    fn.n_tot = fn.call_list.size();
     for (unsigned w = 0; w < n_var; ++w) v.life[w] = v.high_water[w] - v.low_water[w];
     if (!gen_fan_flag) { v.fan_in.clear(); v.fan_out.clear(); }
     if (!quiet) {
@@ -110,7 +152,7 @@ Analysis analyze_bristol(const std::string& in_fname, bool gen_fan_flag, bool ne
                   << "number bits input 1 = " << v.n_in1_bits << "\n"
                   << "number bits input 2 = " << v.n_in2_bits << "\n"
                   << "number bits output 1 = " << v.n_out1_bits << "\n"
-                  << "Total number of function calls " << n_func << "\n"
+                  << "Total number of function calls " << fn.n_tot << "\n"
                   << " number of and " << fn.n_and << "\n number of xor " << fn.n_xor << "\n number of inv " << fn.n_not
                   << "\n number of eq " << fn.n_eq << "\n number of weqw " << fn.n_eqw << std::endl;
         if (gen_fan_flag && n_var) {
@@ -140,6 +182,12 @@ std::string assemble_bristol(const Analysis& analysis, unsigned max_depth, bool 
     std::fprintf(fid, "# number input1 bits %d\n", v.n_in1_bits);
     std::fprintf(fid, "# number input2 bits %d\n", v.n_in2_bits);
     std::fprintf(fid, "# number output1 bits %d\n", v.n_out1_bits);
+    for (size_t k = 2; k < v.in_bits.size(); ++k) std::fprintf(fid, "# number input%d bits %d\n", (int)k + 1, v.in_bits[k]);
+    if (v.out_bits.size() > 1) {
+        std::fprintf(fid, "# output buses");
+        for (unsigned w : v.out_bits) std::fprintf(fid, " %d", w);
+        std::fprintf(fid, "\n");
+    }
 
     // registers are never recycled (src/assemble.cpp:212-225): register k = k-th defined node
     std::vector<int> node_reg(v.n_tot, -1);
@@ -151,8 +199,10 @@ std::string assemble_bristol(const Analysis& analysis, unsigned max_depth, bool 
             if (debug_flag) std::fprintf(fid, "# Assigned node %d to R%d\n", first_node + ix, reg);
         }
     };
-    load(1, v.n_in1_bits, 0);
-    load(2, v.n_in2_bits, v.n_in1_bits);
+    {   // input bus k occupies the next in_bits[k] nodes (In3, In4, ... for Bristol Fashion files with more values)
+        unsigned first = 0;
+        for (size_t k = 0; k < v.in_bits.size(); ++k) { load((unsigned)k + 1, v.in_bits[k], first); first += v.in_bits[k]; }
+    }
 
     const unsigned first_out = v.n_tot - v.n_out1_bits;  // outputs are the last nodes (src/assemble.cpp:187-193)
     std::vector<int> out_reg(v.n_out1_bits, -1);
@@ -162,10 +212,30 @@ std::string assemble_bristol(const Analysis& analysis, unsigned max_depth, bool 
             throw std::runtime_error("assemble_bristol: ran out of register storage");
         }
         const unsigned out_node = f.out_list[line_ix].at(0);
+        if (f.call_list[line_ix] == "EQW") {
+            // wire copy: the output node is another name of the input's register (the reference's assembler writes a
+            // parse-error comment here, src/assemble.cpp:370-373, and leaves the node undefined)
+            const int r = node_reg[f.in_list[line_ix].at(0)];
+            if (r < 0) { std::fclose(fid); throw std::runtime_error("assemble_bristol: EQW of an undefined node"); }
+            node_reg[out_node] = r;
+            if (debug_flag) std::fprintf(fid, "# Assigned node %d to R%d\n", out_node, r);
+            if (out_node >= first_out) out_reg[out_node - first_out] = r;
+            continue;
+        }
         const unsigned out_r = reg++;
         node_reg[out_node] = (int)out_r;
         if (debug_flag) std::fprintf(fid, "# Assigned node %d to R%d\n", out_node, out_r);
         std::vector<int> in_r;
+        const std::string& name = f.call_list[line_ix];
+        if (name == " EQ") {
+            // constant register -- an extension of the text format (the reference's assembler has no such line)
+            std::fprintf(fid, "R%d = CONST(%d)\n", out_r, (int)f.in_list[line_ix].at(0));
+            if (out_node >= first_out) {
+                std::fprintf(fid, "# R%d is a terminal output register for out%ld\n", out_r, (long)(out_node - first_out));
+                out_reg[out_node - first_out] = (int)out_r;
+            }
+            continue;
+        }
         for (unsigned w : f.in_list[line_ix]) {
             if (node_reg[w] < 0) {
                 std::fclose(fid);
@@ -173,7 +243,6 @@ std::string assemble_bristol(const Analysis& analysis, unsigned max_depth, bool 
             }
             in_r.push_back(node_reg[w]);
         }
-        const std::string& name = f.call_list[line_ix];
         unsigned depth = 0;
         if (name == "XOR" && in_r.size() == 2) {
             depth = 1;

@@ -19,7 +19,10 @@ struct Variable {
     unsigned n_inputs = 0;
     unsigned n_in1_bits = 0;
     unsigned n_in2_bits = 0;
-    unsigned n_out1_bits = 0;
+    unsigned n_out1_bits = 0;   // ALL output bits (the buses concatenated, first output first)
+    // Bristol Fashion allows any number of input / output values: every bus width, in header order
+    // (the reference hard-codes two inputs and one output, src/analyze.cpp:129-158)
+    std::vector<unsigned> in_bits, out_bits;
     std::vector<unsigned> high_water, low_water, life, fan_in, fan_out;
 };
 
@@ -27,7 +30,9 @@ struct Variable {
 struct Function {
     std::string in_fname;
     uint64_t n_tot = 0;        // function calls (gates)
-    std::vector<std::string> call_list;   // "XOR" / "AND" / "NOT" / "EQW"
+    // "XOR" / "AND" / "NOT" / "EQW" (wire copy) / " EQ" (constant: in_list[i][0] is the literal 0 or 1, not a wire);
+    // a Bristol Fashion MAND line is expanded into its single ANDs
+    std::vector<std::string> call_list;
     std::vector<std::vector<unsigned>> in_list, out_list;
     unsigned n_and = 0, n_or = 0, n_xor = 0, n_not = 0, n_eq = 0, n_eqw = 0;
     std::vector<std::string> names;

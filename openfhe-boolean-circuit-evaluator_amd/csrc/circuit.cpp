@@ -203,15 +203,24 @@ bool Circuit::ReadFile(const std::string& inFname) {
     if (!quiet_) std::cout << "Loading circuit description " << inFname << std::endl;
     std::ifstream in(inFname);
     if (!in) throw std::runtime_error("error opening file " + inFname);
-    inputGates.clear(); allGates.clear(); wire_names_.clear(); wire_of_reg_.clear();
+    inputGates.clear(); constWires_.clear(); allGates.clear(); wire_names_.clear(); wire_of_reg_.clear();
     unsigned lineNo = 0, gateNo = 0, max_out = 0;
     bool any_out = false;
     std::string t;
-    n_buses_ = 0; n_in_bits_[0] = n_in_bits_[1] = 0;
+    n_buses_ = 0; n_in_bits_.assign(2, 0); out_bus_bits_.clear();
     while (std::getline(in, t)) {
         ++lineNo;
         if (!quiet_ && lineNo % 100 == 0) std::cout << "\r loading line " << lineNo << std::flush;
-        if (!t.empty() && t[0] == '#') continue;
+        if (!t.empty() && t[0] == '#') {
+            // "# output buses w1 w2 ...": written by this assembler for circuits with several output values
+            if (t.rfind("# output buses", 0) == 0) {
+                std::istringstream ob(t.substr(14));
+                unsigned w;
+                out_bus_bits_.clear();
+                while (ob >> w) out_bus_bits_.push_back(w);
+            }
+            continue;
+        }
         unsigned n1 = 0, n2 = 0, n3 = 0;
         auto two_in = [&](const char* fmt, const char* what, GateEnum op) {
             if (std::sscanf(t.c_str(), fmt, &n1, &n2, &n3) != 3) throw std::runtime_error(std::string(what) + " parse error line " + std::to_string(lineNo));
@@ -220,11 +229,17 @@ bool Circuit::ReadFile(const std::string& inFname) {
             allGates.push_back(g);
         };
         // dispatch order of the reference reader (src/circuit.cpp:144,171,199,223,246,270,292)
-        if (contains(t, "LOAD")) {
-            if (std::sscanf(t.c_str(), "R%u = LOAD(In%u, %u)", &n1, &n2, &n3) != 3 || n2 < 1 || n2 > 2)
+        if (contains(t, "CONST")) {
+            // extension of the text format (Bristol Fashion EQ): a register holding a public constant
+            if (std::sscanf(t.c_str(), "R%u = CONST(%u)", &n1, &n2) != 2 || n2 > 1)
+                throw std::runtime_error("CONST parse error line " + std::to_string(lineNo));
+            constWires_.push_back({addWire(n1), n2});
+        } else if (contains(t, "LOAD")) {
+            if (std::sscanf(t.c_str(), "R%u = LOAD(In%u, %u)", &n1, &n2, &n3) != 3 || n2 < 1 || n2 > 64)
                 throw std::runtime_error("LOAD parse error line " + std::to_string(lineNo));
             LoadRec l{n2 - 1, n3, addWire(n1), "INPUT:" + std::to_string(gateNo++)};
             n_buses_ = std::max(n_buses_, n2);
+            if (n_in_bits_.size() < n2) n_in_bits_.resize(n2, 0);
             n_in_bits_[n2 - 1] = std::max(n_in_bits_[n2 - 1], n3 + 1);
             inputGates.push_back(l);
         } else if (contains(t, "STORE")) {
@@ -250,6 +265,11 @@ bool Circuit::ReadFile(const std::string& inFname) {
     }
     n_outputs = 1;
     n_output_bits.assign(1, any_out ? max_out + 1 : 0);
+    {
+        unsigned tot = 0;
+        for (unsigned w : out_bus_bits_) tot += w;
+        if (out_bus_bits_.empty() || tot != n_output_bits[0]) out_bus_bits_.assign(1, n_output_bits[0]);
+    }
     if (!quiet_) {
         std::cout << std::endl << "generating output nbits " << n_output_bits[0] << std::endl;
         std::cout << "generating netlist" << std::endl;
@@ -263,20 +283,37 @@ bool Circuit::ReadBristol(const std::string& path, bool new_flag) {
     Analysis A = analyze_bristol(path, false, new_flag, true);
     const Variable& v = A.variables;
     const Function& f = A.functions;
-    inputGates.clear(); allGates.clear(); wire_names_.clear(); wire_of_reg_.clear();
+    inputGates.clear(); constWires_.clear(); allGates.clear(); wire_names_.clear(); wire_of_reg_.clear();
     unsigned gateNo = 0;
-    // same register numbering as the assembler: inputs first, then one register per gate
+    // same register numbering as the assembler: inputs first (bus after bus), then one register per gate
     std::vector<int> node_wire(v.n_tot, -1);
     uint32_t reg = 0;
-    for (unsigned b = 0; b < v.n_in1_bits; ++b) { node_wire[b] = addWire(reg++); inputGates.push_back({0, b, node_wire[b], "INPUT:" + std::to_string(gateNo++)}); }
-    for (unsigned b = 0; b < v.n_in2_bits; ++b) { node_wire[v.n_in1_bits + b] = addWire(reg++); inputGates.push_back({1, b, node_wire[v.n_in1_bits + b], "INPUT:" + std::to_string(gateNo++)}); }
-    n_buses_ = v.n_in2_bits ? 2 : 1;
-    n_in_bits_[0] = v.n_in1_bits; n_in_bits_[1] = v.n_in2_bits;
+    {
+        unsigned node = 0;
+        for (size_t bus = 0; bus < v.in_bits.size(); ++bus)
+            for (unsigned b = 0; b < v.in_bits[bus]; ++b, ++node) {
+                node_wire[node] = addWire(reg++);
+                inputGates.push_back({(unsigned)bus, b, node_wire[node], "INPUT:" + std::to_string(gateNo++)});
+            }
+    }
+    n_in_bits_ = v.in_bits;
+    while (n_in_bits_.size() > 1 && n_in_bits_.back() == 0) n_in_bits_.pop_back();   // old format: "n 0 m" = one input
+    n_buses_ = (unsigned)n_in_bits_.size();
+    if (n_in_bits_.size() < 2) n_in_bits_.resize(2, 0);
+    out_bus_bits_ = v.out_bits;
     for (size_t i = 0; i < f.call_list.size(); ++i) {
         const std::string& op = f.call_list[i];
         GateRec g{};
         g.in[0] = g.in[1] = -1; g.out_bit = -1;
         const auto& il = f.in_list[i];
+        if (op == " EQ") {
+            // constant: a register that is live from the start; encrypted runs hold it as the trivial (noiseless)
+            // ciphertext (0, value * q/4) -- a public constant needs no key
+            const int w = addWire(reg++);
+            node_wire[f.out_list[i].at(0)] = w;
+            constWires_.push_back({w, il.at(0)});
+            continue;
+        }
         for (unsigned w : il) if (node_wire[w] < 0) throw std::runtime_error("ReadBristol: gate " + std::to_string(i) + " uses undefined wire");
         if (op == "XOR" || op == "AND") {
             if (il.size() != 2) throw std::runtime_error("ReadBristol: bad arity");
@@ -301,7 +338,7 @@ bool Circuit::ReadBristol(const std::string& path, bool new_flag) {
         if (w < 0) throw std::runtime_error("ReadBristol: output node never driven");
         allGates.push_back(GateRec{GateEnum::OUTPUT, 1, {w, -1}, -1, (int)o, "OUTPUT:" + std::to_string(gateNo++)});
     }
-    n_outputs = 1;
+    n_outputs = 1;   // internally ONE concatenated bus (bit indices run over all output values); getOutputs() splits it
     n_output_bits.assign(1, v.n_out1_bits);
     finalizeNetlist();
     return true;
@@ -321,6 +358,7 @@ void Circuit::finalizeNetlist() {
     gate_level_.assign(G, -1);
     std::vector<int> ready(G, 0), active;
     for (const auto& l : inputGates) active.push_back(l.wire);
+    for (const auto& k : constWires_) active.push_back(k.wire);
     max_level_xor_ = 0;
     while (!active.empty()) {
         Level L;
@@ -411,6 +449,7 @@ void Circuit::SetInput(unsigned inst, const Inputs& input, bool verbose) {
         bits.push_back(v);
         slots.push_back(inst * stride_ + (uint32_t)l.wire);
     }
+    for (const auto& k : constWires_) plain_[inst][k.wire] = (uint8_t)k.value;
     if (total_bits != inputGates.size())
         std::cerr << "error: total_inputs: " << total_bits << " #used: " << inputGates.size() << std::endl;
     else if (verbose)
@@ -421,6 +460,19 @@ void Circuit::SetInput(unsigned inst, const Inputs& input, bool verbose) {
         // stream index = (evaluation epoch, instance, input position): every rank draws the same ciphertexts
         uint64_t base = ((epoch_ & 0xFFFFFull) << 44) | ((uint64_t)inst << 24);
         ck(bce_encrypt_bits(cc, bits.data(), slots.data(), (uint32_t)slots.size(), base, encrypt_mode_), "SetInput(Encrypt)");
+        if (!constWires_.empty()) {
+            // public constants: trivial ciphertexts (a = 0, b = value * q/4), exact and noiseless
+            uint64_t p[BCE_P_COUNT];
+            ck(bce_get_params(cc, p), "SetInput(params)");
+            const size_t W = (size_t)p[BCE_P_n] + 1;
+            std::vector<uint64_t> cts(constWires_.size() * W, 0);
+            std::vector<uint32_t> cslots;
+            for (size_t k = 0; k < constWires_.size(); ++k) {
+                cts[k * W + W - 1] = constWires_[k].value ? p[BCE_P_q] / 4 : 0;
+                cslots.push_back(inst * stride_ + (uint32_t)constWires_[k].wire);
+            }
+            ck(bce_lwe_write(cc, cslots.data(), (uint32_t)cslots.size(), cts.data()), "SetInput(constants)");
+        }
     }
     inputs_set_ = true;
 }
@@ -866,8 +918,17 @@ Outputs Circuit::Clock() {
 }
 
 Outputs Circuit::getOutputs(unsigned instance) const {
-    Outputs o(1);
-    if (instance < circuitOut.size()) o[0].assign(circuitOut[instance].begin(), circuitOut[instance].end());
+    // one vector per output value (Bristol Fashion circuits may have several; the reference has one, src/circuit.cpp:183-185)
+    Outputs o(std::max<size_t>(1, out_bus_bits_.size()));
+    if (instance >= circuitOut.size()) return o;
+    const auto& bits = circuitOut[instance];
+    size_t pos = 0;
+    for (size_t b = 0; b < out_bus_bits_.size(); ++b) {
+        const size_t w = std::min<size_t>(out_bus_bits_[b], bits.size() - std::min(bits.size(), pos));
+        o[b].assign(bits.begin() + pos, bits.begin() + pos + w);
+        pos += w;
+    }
+    if (out_bus_bits_.empty()) o[0].assign(bits.begin(), bits.end());
     return o;
 }
 
@@ -882,8 +943,8 @@ bce_circuit_info Circuit::info() const {
     I.n_input_gates = (uint32_t)inputGates.size();
     I.n_wires = (uint32_t)wire_names_.size();
     I.n_inputs = n_buses_;
-    I.n_input_bits[0] = n_in_bits_[0];
-    I.n_input_bits[1] = n_in_bits_[1];
+    I.n_input_bits[0] = n_in_bits_.size() > 0 ? n_in_bits_[0] : 0;   // every bus: bce_circuit_get_buses()
+    I.n_input_bits[1] = n_in_bits_.size() > 1 ? n_in_bits_[1] : 0;
     I.n_output_bits = n_output_bits.empty() ? 0 : n_output_bits[0];
     I.n_levels = (uint32_t)levels_.size();
     I.n_relevel_steps = (uint32_t)relevel_plan_.size();

@@ -133,6 +133,8 @@ public:
     void getCounts(uint32_t out[6]) const;
     const bce_circuit_stats& stats() const { return stats_; }
     bce_circuit_info info() const;
+    const std::vector<unsigned>& inputBusBits() const { return n_in_bits_; }
+    const std::vector<unsigned>& outputBusBits() const { return out_bus_bits_; }
     void setExchange(uint32_t rank, uint32_t world, int shard_mode, bce_allgather_fn fn, void* user, void* host_send,
                      void* host_recv, void* dev_send, void* dev_recv, uint64_t capacity);
     uint64_t exchangeCapacity(uint32_t world, int shard_mode, bool encrypted) const;
@@ -148,6 +150,7 @@ private:
         std::string name;
     };
     struct LoadRec { unsigned bus, bit; int wire; std::string name; };
+    struct ConstRec { int wire; unsigned value; };  // Bristol Fashion EQ: a public constant, no gate
     struct Level {
         std::vector<int> gates;  // file order
         uint32_t n_xor = 0;
@@ -161,6 +164,7 @@ private:
     GateEvalParams gep;
 
     std::vector<LoadRec> inputGates;  // LOADs
+    std::vector<ConstRec> constWires_; // constants (live from the start, like inputs)
     std::vector<GateRec> allGates;    // everything else, file order
     std::vector<std::string> wire_names_;
     std::map<uint32_t, int> wire_of_reg_;
@@ -170,7 +174,9 @@ private:
     uint32_t max_level_xor_ = 0, stride_ = 0;
     unsigned n_outputs = 1;
     std::vector<unsigned> n_output_bits;
-    unsigned n_in_bits_[2] = {0, 0}, n_buses_ = 0;
+    std::vector<unsigned> n_in_bits_;      // width of every input bus (In1, In2, ...)
+    std::vector<unsigned> out_bus_bits_;   // width of every output bus; output bit indices run over their concatenation
+    unsigned n_buses_ = 0;
 
     unsigned instances_ = 1;
     std::vector<std::vector<uint8_t>> plain_;       // [instance][wire]

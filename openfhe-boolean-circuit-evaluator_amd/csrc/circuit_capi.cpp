@@ -99,8 +99,21 @@ int bce_circuit_clock(bce_circuit* h) { return guarded(h, [&] { h->c.Clock(); })
 int bce_circuit_get_output(const bce_circuit* h, uint32_t instance, uint8_t* bits) {
     if (!h || !bits) return BCE_ERR_ARG;
     if (instance >= h->c.getInstances()) return BCE_ERR_ARG;
-    bce::Outputs o = h->c.getOutputs(instance);
-    for (size_t i = 0; i < o[0].size(); ++i) bits[i] = (uint8_t)o[0][i];
+    bce::Outputs o = h->c.getOutputs(instance);   // all output values, concatenated in header order
+    size_t pos = 0;
+    for (const auto& bus : o)
+        for (unsigned b : bus) bits[pos++] = (uint8_t)b;
+    return BCE_OK;
+}
+int bce_circuit_get_buses(const bce_circuit* h, uint32_t* n_in, uint32_t* in_widths, uint32_t in_cap, uint32_t* n_out,
+                          uint32_t* out_widths, uint32_t out_cap) {
+    if (!h || !n_in || !n_out) return BCE_ERR_ARG;
+    const auto& iw = h->c.inputBusBits();
+    const auto& ow = h->c.outputBusBits();
+    *n_in = (uint32_t)iw.size();
+    *n_out = (uint32_t)ow.size();
+    for (uint32_t k = 0; in_widths && k < in_cap && k < iw.size(); ++k) in_widths[k] = iw[k];
+    for (uint32_t k = 0; out_widths && k < out_cap && k < ow.size(); ++k) out_widths[k] = ow[k];
     return BCE_OK;
 }
 int bce_circuit_get_counts(const bce_circuit* h, uint32_t out[6]) {

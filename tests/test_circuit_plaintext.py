@@ -214,7 +214,7 @@ def _bits(v, n):
 
 def test_new_format_arithmetic_circuits(bce):
     """Bristol Fashion (new format) circuits read directly: 2 inputs / 1 output, EQW wire copies (neg64) and
-    two outputs concatenated on the single output bus (mult2_64).  LSB-first wires."""
+    two output values (mult2_64: Outputs[0] = high half, Outputs[1] = low half).  LSB-first wires."""
     import random
     rnd = random.Random(7)
     M = (1 << 64) - 1
@@ -231,8 +231,12 @@ def test_new_format_arithmetic_circuits(bce):
         assert run("sub64.txt", a, b)[0] == (a - b) & M
         assert run("neg64.txt", a)[0] == (-a) & M
         assert run("mult64.txt", a, b)[0] == (a * b) & M
-        got, info = run("mult2_64.txt", a, b)          # two 64-bit outputs: high half first, then low half
-        assert info["n_output_bits"] == 128 and got == ((a * b) >> 64) | (((a * b) & M) << 64)
+        c2 = bce.Circuit()
+        c2.ReadBristol(os.path.join(CIRCUITS, "mult2_64.txt"), new_flag=True)
+        c2.Reset(); c2.setPlaintext(True); c2.SetInput([_bits(a, 64), _bits(b, 64)])
+        outs = c2.Clock()                              # two 64-bit output values: high half first, then low half
+        assert c2.info()["n_output_bits"] == 128 and c2.info()["output_buses"] == [64, 64] and len(outs) == 2
+        assert kat.to_int(outs[0]) == (a * b) >> 64 and kat.to_int(outs[1]) == (a * b) & M
     assert run("zero_equal.txt", 0)[0] == 1 and run("zero_equal.txt", 5)[0] == 0
 
 
@@ -293,3 +297,62 @@ def test_new_format_aes128(bce):
         c.Clock()
         assert sum(b << i for i, b in enumerate(c.Outputs(0)[0])) == int(ct, 16)
 
+
+
+BF_MAJ3 = """8 14
+3 2 2 1
+2 2 1
+
+1 1 1 5 EQ
+1 1 0 6 EQ
+4 2 0 1 2 3 7 8 MAND
+2 1 7 5 9 AND
+2 1 8 6 10 XOR
+2 1 9 4 11 XOR
+1 1 10 12 EQW
+2 1 5 4 13 XOR
+"""
+
+
+def test_bristol_fashion_eq_mand_three_inputs_two_outputs(bce, tmp_path):
+    """The parts of the Bristol Fashion format none of the reference's own circuit files use and its analyzer
+    rejects or ignores (src/analyze.cpp:129-158 reads two input widths and one output width; :273-277 exits on
+    EQ): constant wires (EQ), MAND (m ANDs on one line), three input values, two output values.
+    Inputs x (wires 0,1), y (2,3), z (4).  w5 = 1, w6 = 0, (w7, w8) = (x0 & y0, x1 & y1), w9 = w7 & 1,
+    w10 = w8 ^ 0, w11 = w9 ^ z, w12 = EQW(w10), w13 = 1 ^ z; outputs are the last 3 wires:
+    value 0 = (w11, w12), value 1 = (w13)."""
+    path = tmp_path / "bf.txt"
+    path.write_text(BF_MAJ3)
+    c = bce.Circuit()
+    c.ReadBristol(str(path), new_flag=True)
+    info = c.info()
+    assert info["n_input_bits"] == [2, 2, 1] and info["output_buses"] == [2, 1] and info["n_output_bits"] == 3
+    assert info["n_bootstraps"] == 2 + 1 + 3 * 3          # MAND = 2 ANDs, one AND, three XORs
+    for x in range(4):
+        for y in range(4):
+            for z in range(2):
+                c.Reset(); c.setPlaintext(True)
+                c.SetInput([_bits(x, 2), _bits(y, 2), [z]])
+                outs = c.Clock()
+                a0, a1 = (x & y) & 1, ((x >> 1) & (y >> 1)) & 1
+                assert outs == [[a0 ^ z, a1], [1 ^ z]], (x, y, z, outs)
+    # the same netlist through the assembler text format (CONST lines, In3 loads, output-bus comment)
+    out = str(tmp_path / "bf_FHE.out")
+    bce.assemble_bristol(str(path), out, new_flag=True)
+    txt = open(out).read()
+    assert "CONST(1)" in txt and "LOAD(In3,0)" in txt and "# output buses 2 1" in txt
+    d = bce.Circuit()
+    d.ReadFile(out)
+    assert d.info()["n_input_bits"] == [2, 2, 1] and d.info()["output_buses"] == [2, 1]
+    d.Reset(); d.setPlaintext(True); d.SetInput([[1, 1], [1, 0], [1]])
+    assert d.Clock() == [[0, 0], [0]]
+    d.Reset(); d.setPlaintext(True); d.SetInput([[1, 1], [1, 1], [0]])
+    assert d.Clock() == [[1, 1], [1]]
+    # malformed lines are rejected with a message, not a crash
+    bad = tmp_path / "bad.txt"
+    bad.write_text(BF_MAJ3.replace("1 1 1 5 EQ", "1 1 2 5 EQ"))
+    with pytest.raises(bce.BceError):
+        bce.Circuit().ReadBristol(str(bad), new_flag=True)
+    bad.write_text(BF_MAJ3.replace("4 2 0 1 2 3 7 8 MAND", "3 2 0 1 2 7 8 MAND"))
+    with pytest.raises(bce.BceError):
+        bce.Circuit().ReadBristol(str(bad), new_flag=True)

@@ -277,3 +277,83 @@ def test_relevelled_schedule_same_ciphertexts_fewer_launches(bce, toy_cc, std_cc
     assert _enc_run(m, kat.aes_case(v)[0]) == kat.aes_case(v)[1]
     st = m.stats()
     assert st["bootstraps"] == 66415 and st["sublaunches"] == 416 + 0 and st["levels"] == 416
+
+
+def test_ieee754_circuits_encrypted_std128(bce, std_cc):
+    """The reference's Bristol Fashion floating-point corpus under encryption (bootstrap-depth schedule, three
+    operand pairs in lock-step): binary64 add (29,955 bootstraps / evaluation), mul (85,467) and double -> int64
+    (6,342), pinned against the host's own IEEE-754 arithmetic."""
+    import struct
+    d2u = lambda x: struct.unpack("<Q", struct.pack("<d", x))[0]
+    bits = lambda v, n: [(v >> i) & 1 for i in range(n)]
+    val = lambda b: sum(x << i for i, x in enumerate(b))
+    pairs = [(1.5, 2.25), (0.1, 0.2), (1e10, -3.5)]
+    for name, fn in (("FP-add.txt", lambda a, b: a + b), ("FP-mul.txt", lambda a, b: a * b)):
+        c = bce.Circuit(std_cc)
+        c.ReadBristol(os.path.join(CIRCUITS, name), new_flag=True)
+        c.setInstances(len(pairs))
+        c.Reset()
+        c.setEncrypted(True)
+        c.setRelevel(True)
+        for k, (a, b) in enumerate(pairs):
+            c.SetInput([bits(d2u(a), 64), bits(d2u(b), 64)], instance=k)
+        c.Clock()
+        for k, (a, b) in enumerate(pairs):
+            assert val(c.Outputs(k)[0]) == d2u(fn(a, b)), (name, a, b)
+    f = bce.Circuit(std_cc)
+    f.ReadBristol(os.path.join(CIRCUITS, "FP-f2i.txt"), new_flag=True)
+    xs = [3.7, -2.5, 123456789.5]
+    f.setInstances(len(xs))
+    f.Reset()
+    f.setEncrypted(True)
+    f.setRelevel(True)
+    for k, x in enumerate(xs):
+        f.SetInput([bits(d2u(x), 64)], instance=k)
+    f.Clock()
+    for k, x in enumerate(xs):
+        assert val(f.Outputs(k)[0]) == int(np.rint(x)) & ((1 << 64) - 1), x
+
+
+BF_CONST = """8 14
+3 2 2 1
+2 2 1
+
+1 1 1 5 EQ
+1 1 0 6 EQ
+4 2 0 1 2 3 7 8 MAND
+2 1 7 5 9 AND
+2 1 8 6 10 XOR
+2 1 9 4 11 XOR
+1 1 10 12 EQW
+2 1 5 4 13 XOR
+"""
+
+
+@pytest.mark.parametrize("relevel", [False, True])
+def test_bristol_fashion_constants_mand_buses_encrypted(bce, orc, toy_cc, tmp_path, relevel):
+    """EQ constants enter an encrypted evaluation as trivial ciphertexts (a = 0, b = value q/4): gates on them must
+    come out as the oracle computes them on the same ciphertexts; MAND, three input values, two output values
+    (netlist of tests/test_circuit_plaintext.py::test_bristol_fashion_eq_mand_three_inputs_two_outputs)."""
+    path = tmp_path / "bf.txt"
+    path.write_text(BF_CONST)
+    c = bce.Circuit(toy_cc)
+    c.ReadBristol(str(path), new_flag=True)
+    c.setInstances(4)
+    c.Reset()
+    c.setEncrypted(True)
+    c.setRelevel(relevel)
+    cases = [(3, 3, 0), (1, 3, 1), (2, 1, 1), (0, 0, 0)]
+    for k, (x, y, z) in enumerate(cases):
+        c.SetInput([[x & 1, x >> 1], [y & 1, y >> 1], [z]], instance=k)
+    c.Clock()
+    for k, (x, y, z) in enumerate(cases):
+        a0, a1 = (x & y) & 1, ((x >> 1) & (y >> 1)) & 1
+        assert c.Outputs(k) == [[a0 ^ z, a1], [1 ^ z]], (x, y, z)
+    # ciphertext level: register 5 is the constant 1 (trivial), register 9 = AND(register 7, register 5)
+    o = orc.Oracle(orc.TOY, orc.GINX)
+    o.keygen(0x0FE5EED)
+    stride = c.info()["slot_stride"]
+    regs = toy_cc.lwe_read(np.arange(0, 11, dtype=np.uint32) + 1 * stride)     # instance 1; wires 0..4 inputs, 5, 6 constants
+    q = o.params["q"]
+    assert not regs[5][:-1].any() and regs[5][-1] == q // 4 and not regs[6].any()
+    assert np.array_equal(regs[9], o.eval_bingate(orc.AND, regs[7], regs[5]))
