@@ -111,6 +111,11 @@ int bce_keygen(bce_ctx*, const uint8_t seed[32]);
  * (GINX) or [i][v][k][row][col][N] (AP); ksk [i][v][j][n+1] mod qKS. */
 int bce_import_keys(bce_ctx*, const int32_t* s, const int32_t* z, const uint64_t* bsk, uint64_t bsk_words,
                     const uint32_t* ksk, uint64_t ksk_words);
+/* The same material from / to a file in the format of tools/openfhe_export/bce_keyfile.h -- what the
+ * OpenFHE-side exporter (tools/openfhe_export/export_keys.cpp) writes for the keys of an existing deployment
+ * (cc.KeyGen() / cc.BTKeyGen(sk), src/circuit.cpp:90-91).  Parameters in the file must match the context. */
+int bce_import_keys_file(bce_ctx*, const char* path);
+int bce_export_keys_file(bce_ctx*, const char* path);
 uint64_t bce_bsk_words(const bce_ctx*);
 uint64_t bce_ksk_words(const bce_ctx*);
 int bce_export_sk(const bce_ctx*, int32_t* s, int32_t* z);

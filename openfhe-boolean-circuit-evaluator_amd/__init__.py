@@ -53,7 +53,7 @@ class Timing(C.Structure):
 
 ENGINE_SYMBOLS = [
     "bce_ctx_create", "bce_ctx_create_custom", "bce_ctx_destroy", "bce_last_error", "bce_get_params",
-    "bce_keygen", "bce_import_keys", "bce_bsk_words", "bce_ksk_words", "bce_export_sk", "bce_export_bsk",
+    "bce_keygen", "bce_import_keys", "bce_import_keys_file", "bce_export_keys_file", "bce_bsk_words", "bce_ksk_words", "bce_export_sk", "bce_export_bsk",
     "bce_export_ksk", "bce_pool_reserve", "bce_pool_slots", "bce_lwe_write", "bce_lwe_read",
     "bce_encrypt_bits", "bce_set_encrypt_seed", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize",
     "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_debug_eval_stages", "bce_debug_ntt",
@@ -86,6 +86,8 @@ def lib():
     L.bce_get_params.argtypes = [vp, C.POINTER(u64)]
     L.bce_keygen.argtypes = [vp, C.c_char_p]
     L.bce_import_keys.argtypes = [vp, vp, vp, vp, u64, vp, u64]
+    L.bce_import_keys_file.argtypes = [vp, C.c_char_p]
+    L.bce_export_keys_file.argtypes = [vp, C.c_char_p]
     L.bce_bsk_words.argtypes = [vp]
     L.bce_bsk_words.restype = u64
     L.bce_ksk_words.argtypes = [vp]
@@ -181,6 +183,13 @@ class BinFHEContext:
         bsk = np.ascontiguousarray(bsk, dtype=np.uint64)
         ksk = np.ascontiguousarray(ksk, dtype=np.uint32)
         self._ck(self._L.bce_import_keys(self.h, _p(s), _p(z), _p(bsk), bsk.size, _p(ksk), ksk.size))
+
+    def import_keys_file(self, path):
+        """keys written by tools/openfhe_export/export_keys.cpp (format: tools/openfhe_export/bce_keyfile.h)"""
+        self._ck(self._L.bce_import_keys_file(self.h, os.fsencode(path)))
+
+    def export_keys_file(self, path):
+        self._ck(self._L.bce_export_keys_file(self.h, os.fsencode(path)))
 
     def export_sk(self):
         s = np.zeros(self.n, dtype=np.int32)

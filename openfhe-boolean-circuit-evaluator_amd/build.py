@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libbce_amd.so")
 OBJ = os.path.join(HERE, "_obj")
 
-SOURCES = ["kernels.hip", "kernels64.hip", "keygen.hip", "engine.cpp", "bristol.cpp", "circuit.cpp", "circuit_capi.cpp"]
+SOURCES = ["kernels.hip", "kernels64.hip", "keygen.hip", "engine.cpp", "keyfile.cpp", "bristol.cpp", "circuit.cpp", "circuit_capi.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-Wall",
          "-Wno-unused-result", "-Wno-unused-value"]
 FLAGS += os.environ.get("BCE_EXTRA_FLAGS", "").split()  # development builds only (e.g. -DBCE_PHASE_PROF)
@@ -21,6 +21,7 @@ FLAGS += os.environ.get("BCE_EXTRA_FLAGS", "").split()  # development builds onl
 def _deps():
     paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     paths += [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))]
+    paths.append(os.path.join(HERE, "..", "tools", "openfhe_export", "bce_keyfile.h"))
     return paths
 
 

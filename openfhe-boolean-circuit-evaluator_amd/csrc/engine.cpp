@@ -603,6 +603,11 @@ void bce_ctx_destroy(bce_ctx* c) {
     delete c;
 }
 
+int bce_set_error(bce_ctx* c, int code, const char* msg) {  // for the other translation units of the library (keyfile.cpp)
+    if (c) c->err = msg ? msg : "";
+    return code;
+}
+
 const char* bce_last_error(const bce_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 int bce_get_params(const bce_ctx* c, uint64_t out[BCE_P_COUNT]) {

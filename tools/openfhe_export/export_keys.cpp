@@ -1,0 +1,149 @@
+// export_keys.cpp -- OpenFHE-side exporter: writes the key material of an lbcrypto::BinFHEContext in the exchange
+// format of bce_keyfile.h, which libbce_amd.so loads with bce_import_keys_file().
+//
+// WHY: the reference draws its keys with cc.KeyGen() / cc.BTKeyGen(sk) (/root/reference/src/circuit.cpp:90-91) from
+// OpenFHE's unseeded PRNG.  Feeding the SAME keys and ciphertexts to the engine is the only way to state
+// "bit-exact against the reference's own encrypted path"; this program is the producer side of that comparison.
+//
+// STATUS: OpenFHE (and Boost, which the reference also needs) are not installed in the environment this repository
+// is developed in, so this file has NOT been compiled there.  It is written against the public binfhe API of
+// openfhe-development v1.0.x (the version the reference names, Release_Notes.md:4):
+//   BinFHEContext::GetParams(), GetRefreshKey() -> RingGSWACCKey, GetSwitchKey() -> LWESwitchingKey,
+//   RingGSWACCKeyImpl::operator[] ([0][key][i] for GINX, [i][v][k] for AP),
+//   RingGSWEvalKeyImpl::GetElements() -> std::vector<std::vector<NativePoly>> (EVALUATION format),
+//   LWESwitchingKeyImpl::GetElementsA() / GetElementsB(), LWEPrivateKeyImpl::GetElement().
+// The consumer side (the file format, its loader and the parity of keys loaded from such a file) IS tested:
+// tests/test_gpu_keyfile.py writes the same format from the CPU oracle's keys.
+//
+// build (on a machine with OpenFHE >= 1.0.1 installed):
+//   cmake -S tools/openfhe_export -B build_export && cmake --build build_export
+// usage:
+//   export_keys <TOY|STD128_OPT|...> <AP|GINX> <keys.bce> [<ciphertexts.bin> <bit> ...]
+//     generates a context + keys exactly like the reference's Circuit constructor, writes the keys, and
+//     optionally encrypts the given bits and appends them as u64[n+1] words each (a_0..a_{n-1}, b) mod q,
+//     the layout bce_lwe_write() takes.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "binfhecontext.h"
+
+#include "bce_keyfile.h"
+
+using namespace lbcrypto;
+
+namespace {
+
+void put(FILE* f, const void* p, size_t bytes) {
+    if (std::fwrite(p, 1, bytes, f) != bytes) throw std::runtime_error("short write");
+}
+
+uint32_t digit_count(double modulus, double base) { return (uint32_t)std::ceil(std::log(modulus) / std::log(base)); }
+
+// one RGSW ciphertext: R rows x 2 polynomials, COEFFICIENT representation, natural coefficient order
+void put_rgsw(FILE* f, const RingGSWEvalKey& ek, uint32_t N) {
+    std::vector<uint64_t> words(N);
+    for (const auto& row : ek->GetElements())
+        for (NativePoly poly : row) {  // by value: SetFormat on a copy
+            poly.SetFormat(Format::COEFFICIENT);
+            for (uint32_t k = 0; k < N; ++k) words[k] = poly[k].ConvertToInt();
+            put(f, words.data(), N * sizeof(uint64_t));
+        }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 4) {
+        std::fprintf(stderr, "usage: %s <paramset> <AP|GINX> <keys.bce> [<cts.bin> <bit> ...]\n", argv[0]);
+        return 2;
+    }
+    const std::map<std::string, BINFHE_PARAMSET> sets = {
+        {"TOY", TOY}, {"MEDIUM", MEDIUM}, {"STD128_AP", STD128_AP}, {"STD128_APOPT", STD128_APOPT}, {"STD128", STD128},
+        {"STD128_OPT", STD128_OPT}, {"STD192", STD192}, {"STD192_OPT", STD192_OPT}, {"STD256", STD256}, {"STD256_OPT", STD256_OPT}};
+    const auto ps = sets.find(argv[1]);
+    if (ps == sets.end()) throw std::invalid_argument("unknown parameter set");
+    const BINFHE_METHOD method = std::string(argv[2]) == "AP" ? AP : GINX;
+
+    // exactly the reference's sequence (src/circuit.cpp:65,88-91)
+    BinFHEContext cc;
+    cc.GenerateBinFHEContext(ps->second, method);
+    LWEPrivateKey sk = cc.KeyGen();
+    cc.BTKeyGen(sk);
+
+    const auto params = cc.GetParams();
+    const auto lwe = params->GetLWEParams();
+    const auto rgsw = params->GetRingGSWParams();
+    const uint32_t n = lwe->Getn(), N = lwe->GetN();
+    const uint64_t q = lwe->Getq().ConvertToInt(), Q = lwe->GetQ().ConvertToInt(), qKS = lwe->GetqKS().ConvertToInt();
+    const uint32_t baseKS = lwe->GetBaseKS(), baseG = rgsw->GetBaseG(), baseR = rgsw->GetBaseR();
+    const uint32_t dG = digit_count((double)Q, (double)baseG), R = 2 * dG;
+    const uint32_t dR = digit_count((double)q, (double)baseR), dKS = digit_count((double)qKS, (double)baseKS);
+
+    bce_keyfile_header h{};
+    std::memcpy(h.magic, BCE_KEYFILE_MAGIC, 8);
+    h.version = BCE_KEYFILE_VERSION;
+    h.method = method == AP ? 1 : 2;
+    h.n = n; h.N = N; h.q = q; h.Q = Q; h.qKS = qKS; h.baseKS = baseKS; h.baseG = baseG; h.baseR = baseR;
+    h.bsk_words = (method == AP ? (uint64_t)n * baseR * dR : (uint64_t)n * 2) * R * 2 * N;
+    h.ksk_words = (uint64_t)N * baseKS * dKS * (n + 1);
+    h.has_z = 0;  // BTKeyGen does not keep the ring secret; evaluation does not need it
+
+    FILE* f = std::fopen(argv[3], "wb");
+    if (!f) throw std::runtime_error("cannot open the key file for writing");
+    put(f, &h, sizeof h);
+    {   // ternary LWE secret, centred
+        std::vector<int32_t> s(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t v = sk->GetElement()[i].ConvertToInt();
+            s[i] = v == 0 ? 0 : (v == 1 ? 1 : -1);
+        }
+        put(f, s.data(), n * sizeof(int32_t));
+        if ((n * sizeof(int32_t)) % 8) { const uint32_t zero = 0; put(f, &zero, 4); }
+    }
+    const RingGSWACCKey ek = cc.GetRefreshKey();
+    if (method == GINX) {
+        // rgsw-acc-cggi.cpp KeyGenAcc: (*ek)[0][0][i] encrypts (s_i == 1), (*ek)[0][1][i] encrypts (s_i == -1)
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t key = 0; key < 2; ++key) put_rgsw(f, (*ek)[0][key][i], N);
+    } else {
+        // rgsw-acc-dm.cpp KeyGenAcc: (*ek)[i][v][k] encrypts X^{s_i * v * baseR^k * 2N/q}; the v = 0 entries are unused
+        std::vector<uint64_t> zeros((size_t)R * 2 * N, 0);
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t v = 0; v < baseR; ++v)
+                for (uint32_t k = 0; k < dR; ++k) {
+                    if (v == 0) put(f, zeros.data(), zeros.size() * sizeof(uint64_t));
+                    else put_rgsw(f, (*ek)[i][v][k], N);
+                }
+    }
+    const LWESwitchingKey ks = cc.GetSwitchKey();
+    {
+        std::vector<uint32_t> row(n + 1);
+        for (uint32_t i = 0; i < N; ++i)
+            for (uint32_t v = 0; v < baseKS; ++v)
+                for (uint32_t j = 0; j < dKS; ++j) {
+                    for (uint32_t k = 0; k < n; ++k) row[k] = (uint32_t)ks->GetElementsA()[i][v][j][k].ConvertToInt();
+                    row[n] = (uint32_t)ks->GetElementsB()[i][v][j].ConvertToInt();
+                    put(f, row.data(), row.size() * sizeof(uint32_t));
+                }
+    }
+    std::fclose(f);
+
+    if (argc >= 6) {  // ciphertexts for a gate-level comparison: u64[n+1] each
+        FILE* c = std::fopen(argv[4], "wb");
+        if (!c) throw std::runtime_error("cannot open the ciphertext file for writing");
+        std::vector<uint64_t> words(n + 1);
+        for (int a = 5; a < argc; ++a) {
+            const LWECiphertext ct = cc.Encrypt(sk, std::atoi(argv[a]), FRESH);
+            for (uint32_t k = 0; k < n; ++k) words[k] = ct->GetA()[k].ConvertToInt();
+            words[n] = ct->GetB().ConvertToInt();
+            put(c, words.data(), words.size() * sizeof(uint64_t));
+        }
+        std::fclose(c);
+    }
+    return 0;
+}
