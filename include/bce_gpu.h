@@ -82,6 +82,8 @@ typedef struct bce_timing {
     double   br_ms[BCE_BR_KERNELS];
     uint64_t br_launches[BCE_BR_KERNELS];
     uint64_t br_bootstraps[BCE_BR_KERNELS];
+    uint64_t fused_tail_launches; /* launches whose blind-rotation kernel also ran the tail in its epilogue
+                                     (their tail time is inside blind_rotate_ms, not tail_ms) */
 } bce_timing;
 
 /* ---- context ----------------------------------------------------------- */

@@ -48,7 +48,8 @@ BR_KERNEL_NAMES = ["k_blind_rotate (one wave per transform)", "k_blind_rotate_la
 class Timing(C.Structure):
     _fields_ = [("blind_rotate_ms", C.c_double), ("tail_ms", C.c_double),
                 ("blind_rotate_launches", C.c_uint64), ("bootstraps", C.c_uint64),
-                ("br_ms", C.c_double * 4), ("br_launches", C.c_uint64 * 4), ("br_bootstraps", C.c_uint64 * 4)]
+                ("br_ms", C.c_double * 4), ("br_launches", C.c_uint64 * 4), ("br_bootstraps", C.c_uint64 * 4),
+                ("fused_tail_launches", C.c_uint64)]
 
 
 ENGINE_SYMBOLS = [
@@ -267,6 +268,7 @@ class BinFHEContext:
         self._ck(self._L.bce_timing_get(self.h, C.byref(t)))
         return {"blind_rotate_ms": t.blind_rotate_ms, "tail_ms": t.tail_ms,
                 "blind_rotate_launches": int(t.blind_rotate_launches), "bootstraps": int(t.bootstraps),
+                "fused_tail_launches": int(t.fused_tail_launches),
                 "by_kernel": [{"kernel": BR_KERNEL_NAMES[k], "ms": t.br_ms[k], "launches": int(t.br_launches[k]),
                                "bootstraps": int(t.br_bootstraps[k])} for k in range(4)]}
 

@@ -242,6 +242,8 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
         P.cu_count = (u32)cus;
+        const char* ft = std::getenv("BCE_FUSE_TAIL");  // development / parity knob: 0 keeps the separate tail kernels
+        P.fuse_tail = (ft && ft[0] == '0') ? 0 : 1;
     }
     {
         u64 I = pow_mod(c->psi, N / 2, Q), v = 1;
@@ -505,35 +507,40 @@ int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances,
         int slot = 0;
         rc = stage_descs(c, boot.data(), boot.size(), &dd, &slot);
         if (rc) return rc;
+        u32 *d_lweN = nullptr, *d_ks = nullptr;
+        if (dbg_lweN) HIP_TRY(c, hipMalloc(&d_lweN, nb * (c->N + 1) * sizeof(u32)));
+        if (dbg_ks) HIP_TRY(c, hipMalloc(&d_ks, nb * (c->n + 1) * sizeof(u32)));
         EventPair e0 = get_events(c, 0);
         int kid = BCE_BR_WORD64;
+        bool tail_fused = false;
         hipEventRecord(e0.a, c->stream);
         if (c->is64) HIP_TRY(c, launch_blind_rotate64(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u64*>(c->d_acc), c->stream));
-        else HIP_TRY(c, launch_blind_rotate(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u32*>(c->d_acc), c->stream, &kid));
+        else HIP_TRY(c, launch_blind_rotate(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u32*>(c->d_acc), c->stream, &kid, d_lweN, d_ks, &tail_fused));
         hipEventRecord(e0.b, c->stream);
         e0.kind = kid;
         c->pending.push_back(e0);
         c->timing.br_launches[kid] += 1;
         c->timing.br_bootstraps[kid] += nb;
-        u32 *d_lweN = nullptr, *d_ks = nullptr;
-        if (dbg_lweN) HIP_TRY(c, hipMalloc(&d_lweN, nb * (c->N + 1) * sizeof(u32)));
-        if (dbg_ks) HIP_TRY(c, hipMalloc(&d_ks, nb * (c->n + 1) * sizeof(u32)));
-        EventPair e1 = get_events(c, BCE_BR_KERNELS);  // kind >= BCE_BR_KERNELS: tail
-        hipEventRecord(e1.a, c->stream);
-        {
-            const size_t need = tail_partial_words(c->P, (u32)nb);
-            if (need > c->tail_cap) {
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                if (c->d_tail_partial) hipFree(c->d_tail_partial);
-                c->d_tail_partial = nullptr;
-                const size_t cap = std::max(need, c->tail_cap * 2);
-                HIP_TRY(c, hipMalloc(&c->d_tail_partial, cap * sizeof(u64)));
-                c->tail_cap = cap;
+        if (!tail_fused) {
+            EventPair e1 = get_events(c, BCE_BR_KERNELS);  // kind >= BCE_BR_KERNELS: tail
+            hipEventRecord(e1.a, c->stream);
+            {
+                const size_t need = tail_partial_words(c->P, (u32)nb);
+                if (need > c->tail_cap) {
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    if (c->d_tail_partial) hipFree(c->d_tail_partial);
+                    c->d_tail_partial = nullptr;
+                    const size_t cap = std::max(need, c->tail_cap * 2);
+                    HIP_TRY(c, hipMalloc(&c->d_tail_partial, cap * sizeof(u64)));
+                    c->tail_cap = cap;
+                }
             }
+            HIP_TRY(c, launch_tail(c->P, dd, (u32)boot.size(), instances, slot_stride, c->d_acc, c->d_tail_partial, d_lweN, d_ks, c->stream));
+            hipEventRecord(e1.b, c->stream);
+            c->pending.push_back(e1);
+        } else {
+            c->timing.fused_tail_launches += 1;
         }
-        HIP_TRY(c, launch_tail(c->P, dd, (u32)boot.size(), instances, slot_stride, c->d_acc, c->d_tail_partial, d_lweN, d_ks, c->stream));
-        hipEventRecord(e1.b, c->stream);
-        c->pending.push_back(e1);
         hipEventRecord(c->ring_ev[slot], c->stream);
         c->ring_busy[slot] = true;
         c->timing.blind_rotate_launches += 1;

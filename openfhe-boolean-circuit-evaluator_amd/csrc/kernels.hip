@@ -478,6 +478,15 @@ __device__ __forceinline__ uint4 bsk_row(__amdgpu_buffer_rsrc_t rsrc, u32 voff, 
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// LWEEncryptionScheme::RoundqQ restated with the same three IEEE double operations
+// (compiled with -ffp-contract=off): floor(0.5 + double(v) * double(q) / double(Q)) mod q
+__device__ __forceinline__ u32 round_qQ(u64 v, u32 q, u64 Qfrom) {
+    double t = (double)v * (double)q;
+    t = t / (double)Qfrom;
+    u64 r = (u64)floor(0.5 + t);
+    return (u32)(r >= q ? r - q : r);
+}
+
 // gate constant q1 of BootstrapGateCore (OR 5q/8, AND 7q/8, NOR q/8, NAND 3q/8)
 __device__ __forceinline__ u32 gate_const(u32 op, u32 q) {
     u32 e = q >> 3;
@@ -930,11 +939,107 @@ __device__ __forceinline__ void split_inverse_rest(const SplitInv<REGTW>& S, con
     else inv_pass4_last(x, twf[tw_pos<2>(1)], twf[tw_pos<2>(0)], ninv, wlast, Q);
 }
 
+// ---- tail of EvalBinGate fused into the blind-rotation kernel (saturated launches) ------------------------------
+// After the last inverse transform the workgroup that ran the blind rotation also extracts the LWE sample,
+// switches it to qKS, gathers its N*dKS key-switching rows and writes the refreshed ciphertext: the same arithmetic
+// as k_tail_gather / k_tail_finish below (one workgroup per bootstrap, S = 1), but its row gather -- memory-bound,
+// 2 MB per bootstrap for STD128 -- runs while the CU's other workgroup keeps the vector ALUs busy, instead of as a
+// separate kernel between two dependent blind-rotation launches.
+//   coef : [2][N] coefficient-form accumulator in LDS        rowidx : [N * dKS] row numbers in LDS
+//   red  : [SL][Gv * VW] u64 partial sums in LDS (SL row slices, one per RW = ceil(Gv / 64) waves)
+// T threads (a multiple of 64); every thread of the workgroup must call it.
+template <typename KT, u32 T>
+__device__ __forceinline__ void fused_tail(const DevParams& P, const u32* coef, u32* rowidx, u64* red, u32* out, u32 boot,
+                                           u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
+    constexpr u32 VW = 16 / sizeof(KT), W = T / 64;
+    const u32 N = P.N, n = P.n, qKS = P.qKS, B = P.baseKS, D = P.dKS, Q = P.Q;
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // transpose (X -> X^-1) of acc[0]: a'_0 = a_0, a'_{N-i} = -a_i; ModSwitch(Q -> qKS); digits -> row numbers
+    for (u32 i = tid; i < N; i += T) {
+        const u32 src = (i == 0) ? coef[0] : coef[N - i];
+        const u32 v = (i == 0) ? src : (src ? Q - src : 0);
+        u32 at = round_qQ(v, qKS, Q);
+        if (dbg_lweN) dbg_lweN[(size_t)boot * (N + 1) + i] = at;
+        for (u32 j = 0; j < D; ++j) {
+            rowidx[i * D + j] = (i * B + at % B) * D + j;
+            at /= B;
+        }
+    }
+    __syncthreads();
+    const KT* __restrict__ ksk = reinterpret_cast<const KT*>(P.ksk);
+    const u32 G = (n + VW) / VW;                  // 16-byte groups holding elements 0..n
+    const u32 Gv = G < T ? G : T;                 // (n + 1 <= T * VW for every parameter set this kernel serves)
+    const u32 RW = (Gv + 63) / 64, SL = W / RW;   // waves per row, row slices
+    const u32 slice = wave / RW, group = (wave - slice * RW) * 64 + lane;
+    const u32 LR = N * D;
+    if (slice < SL && group < Gv) {
+        u64 tot[VW];
+#pragma unroll
+        for (u32 e = 0; e < VW; ++e) tot[e] = 0;
+        const u32 CH = P.ks_chunk;                // rows whose elements can be summed in 32 bits
+        constexpr u32 U = 8;                      // rows in flight per lane
+        u32 r = slice;
+        while (r < LR) {
+            u32 run[VW];
+#pragma unroll
+            for (u32 e = 0; e < VW; ++e) run[e] = 0;
+            const u32 rend = (LR - r > CH * SL) ? r + CH * SL : LR;
+            auto add_row = [&](uint4 v) {
+                if constexpr (sizeof(KT) == 2) {
+                    run[0] += v.x & 0xFFFFu; run[1] += v.x >> 16; run[2] += v.y & 0xFFFFu; run[3] += v.y >> 16;
+                    run[4] += v.z & 0xFFFFu; run[5] += v.z >> 16; run[6] += v.w & 0xFFFFu; run[7] += v.w >> 16;
+                } else {
+                    run[0] += v.x; run[1] += v.y; run[2] += v.z; run[3] += v.w;
+                }
+            };
+            for (; r + (U - 1) * SL < rend; r += U * SL) {
+                uint4 v[U];
+#pragma unroll
+                for (u32 u = 0; u < U; ++u) {
+                    const u32 row = __builtin_amdgcn_readfirstlane(rowidx[r + u * SL]);
+                    v[u] = reinterpret_cast<const uint4*>(ksk + (size_t)row * P.ksk_stride)[group];
+                }
+#pragma unroll
+                for (u32 u = 0; u < U; ++u) add_row(v[u]);
+            }
+            for (; r < rend; r += SL) {
+                const u32 row = __builtin_amdgcn_readfirstlane(rowidx[r]);
+                add_row(reinterpret_cast<const uint4*>(ksk + (size_t)row * P.ksk_stride)[group]);
+            }
+#pragma unroll
+            for (u32 e = 0; e < VW; ++e) tot[e] += run[e];
+        }
+#pragma unroll
+        for (u32 e = 0; e < VW; ++e) red[(size_t)slice * Gv * VW + group * VW + e] = tot[e];
+    }
+    __syncthreads();
+    // KeySwitch: a' = -sum_rows A[row], b' = b - sum_rows B[row] (mod qKS), b = acc[1][0] + Q/8 + 1 mod-switched;
+    // then ModSwitch(qKS -> q) into the pool
+    for (u32 k = tid; k <= n; k += T) {
+        u64 sum = 0;
+        for (u32 sl = 0; sl < SL; ++sl) sum += red[(size_t)sl * Gv * VW + k];
+        const u32 sm = (u32)(sum % qKS);
+        u32 base = 0;
+        if (k == n) {
+            u32 b = coef[N] + P.Q8p1;
+            b = b >= Q ? b - Q : b;
+            base = round_qQ(b, qKS, Q);
+            if (dbg_lweN) dbg_lweN[(size_t)boot * (N + 1) + N] = base;
+        }
+        const u32 v = base >= sm ? base - sm : base + qKS - sm;
+        if (dbg_ks) dbg_ks[(size_t)boot * (n + 1) + k] = v;
+        out[k] = round_qQ(v, P.q, qKS);
+    }
+}
+
 // AP = true: AP/DM accumulator -- one step per non-zero base-baseR digit of -a_i, a single RGSW key selected by the
 // digit, the product REPLACES the accumulator (no monomials); everything else is shared with GINX.
-template <int DG, int WPS, bool AP = false>  // WPS = waves per SIMD the register budget allows: 2 (one workgroup per CU) or 4 (two)
+// FUSE: the tail of EvalBinGate (extract, ModSwitch, KeySwitch, ModSwitch) runs in this kernel's epilogue (fused_tail).
+template <int DG, int WPS, bool AP = false, bool FUSE = false>  // WPS = waves per SIMD the register budget allows: 2 (one workgroup per CU) or 4 (two)
 __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
-                                                                   u32 slot_stride, u32* __restrict__ acc_out) {
+                                                                   u32 slot_stride, u32* __restrict__ acc_out,
+                                                                   u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
     static_assert(DG == 4, "the split inverse transform is laid out for 8 waves");
     constexpr int LOGN = 10;
     using C = Cfg<LOGN>;
@@ -1094,7 +1199,30 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
         u32* out = acc_out + ((size_t)blockIdx.x * 2 + c) * N + S.t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[256 * r] = x[r];
+        if constexpr (FUSE) {
+            // coefficient-form accumulator into LDS (the evaluation-form copy in `acc` is dead: its pass 0 went to xa)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[c * N + S.t + 256 * r] = x[r];
+        }
     }
+    if constexpr (FUSE) {
+        if constexpr (WPS >= 4) __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        // rowidx and the partial sums live in the digit rows + exchange buffers (54 KiB, all dead now)
+        u32* rowidx = dct;
+        u64* red = reinterpret_cast<u64*>(dct + ((N * P.dKS + 3) & ~3u));
+        u32* outp = P.pool + (size_t)(g.out + soff) * P.pool_stride;
+        if (P.ksk_u16) fused_tail<uint16_t, T>(P, acc, rowidx, red, outp, blockIdx.x, dbg_lweN, dbg_ks);
+        else fused_tail<u32, T>(P, acc, rowidx, red, outp, blockIdx.x, dbg_lweN, dbg_ks);
+    }
+}
+
+// LDS the fused tail needs inside the digit rows + exchange buffers of k_blind_rotate_lat (T = 512 threads)
+bool fused_tail_fits(const DevParams& P) {
+    const size_t N = P.N, NP = N + (N >> 6) * 4, R = 2 * P.dG;
+    const size_t VW = P.ksk_u16 ? 8 : 4, G = (P.n + VW) / VW, Gv = G < 512 ? G : 512, RW = (Gv + 63) / 64, SL = 8 / RW;
+    const size_t need = ((N * P.dKS + 3) & ~(size_t)3) * 4 + SL * Gv * VW * 8;
+    return (size_t)P.n + 1 <= 512 * VW && RW <= 8 && need <= (R * NP + 4 * 1280) * 4;
 }
 
 size_t blind_rotate_lat_lds_bytes(const DevParams& P) {
@@ -1126,8 +1254,9 @@ BrKernel pick_br_dg(u32 dG, bool lazy, int occ, bool ap) {
 }  // namespace
 
 hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
-                               u32* acc_out, hipStream_t s, int* kernel_id) {
+                               u32* acc_out, hipStream_t s, int* kernel_id, u32* dbg_lweN, u32* dbg_ks, bool* tail_fused) {
     if (kernel_id) *kernel_id = BCE_BR_WAVE_PER_TRANSFORM;
+    if (tail_fused) *tail_fused = false;
     const u32 R = 2 * P.dG;
     const dim3 grid(n_desc * instances), block(64 * R);
     const size_t lds = blind_rotate_lds_bytes(P);
@@ -1138,15 +1267,21 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n
         // N = 1024, dG = 4 (STD128 class): the split-transform kernel, with the 256-register budget while the
         // launch leaves every workgroup a CU of its own, else with the 128-register one (two per CU);
         // measured against the one-wave-per-transform kernel over launch sizes 64..6144: tools/kernel_sweep.py
+        using LatKernel = void (*)(DevParams, const bce_gate_desc*, u32, u32, u32*, u32*, u32*);
         const size_t lds_lat = blind_rotate_lat_lds_bytes(P);
         const bool alone = (P.variant == 2) || (P.variant == 0 && grid.x <= P.cu_count);
         const bool x1 = alone && P.variant != 3;
-        if (ap) kern = x1 ? k_blind_rotate_lat<4, 2, true> : k_blind_rotate_lat<4, 4, true>;
-        else kern = x1 ? k_blind_rotate_lat<4, 2, false> : k_blind_rotate_lat<4, 4, false>;
+        // saturated launches run the tail of EvalBinGate in the kernel's epilogue (fused_tail); a launch that leaves
+        // CUs to themselves keeps the separate tail kernels, which spread one bootstrap's row gather over many CUs
+        const bool fuse = !x1 && tail_fused && P.fuse_tail && fused_tail_fits(P);
+        LatKernel lk;
+        if (ap) lk = x1 ? k_blind_rotate_lat<4, 2, true, false> : (fuse ? k_blind_rotate_lat<4, 4, true, true> : k_blind_rotate_lat<4, 4, true, false>);
+        else lk = x1 ? k_blind_rotate_lat<4, 2, false, false> : (fuse ? k_blind_rotate_lat<4, 4, false, true> : k_blind_rotate_lat<4, 4, false, false>);
         if (kernel_id) *kernel_id = x1 ? BCE_BR_SPLIT_X1 : BCE_BR_SPLIT_X2;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lat);
+        if (tail_fused) *tail_fused = fuse;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lat);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, block, lds_lat, s, P, d, n_desc, slot_stride, acc_out);
+        hipLaunchKernelGGL(lk, grid, block, lds_lat, s, P, d, n_desc, slot_stride, acc_out, fuse ? dbg_lweN : nullptr, fuse ? dbg_ks : nullptr);
         return hipGetLastError();
     }
     switch (P.logN) {
@@ -1165,14 +1300,6 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n
 // ---------------------------------------------------------------------------------------
 // tail: extract + ModSwitch + KeySwitch + ModSwitch (one workgroup per bootstrap)
 // ---------------------------------------------------------------------------------------
-// LWEEncryptionScheme::RoundqQ restated with the same three IEEE double operations
-// (compiled with -ffp-contract=off): floor(0.5 + double(v) * double(q) / double(Q)) mod q
-__device__ __forceinline__ u32 round_qQ(u64 v, u32 q, u64 Qfrom) {
-    double t = (double)v * (double)q;
-    t = t / (double)Qfrom;
-    u64 r = (u64)floor(0.5 + t);
-    return (u32)(r >= q ? r - q : r);
-}
 
 // The tail runs as two kernels.
 //   k_tail_gather: grid = bootstraps x S.  Workgroup (boot, s) owns the coefficients i in [s N/S, (s+1) N/S):

@@ -37,6 +37,7 @@ struct DevParams {
     u32 variant;           // blind-rotation kernel choice: 0 automatic; 1 one-wave-per-transform kernel; 2 / 3 split-
                            // transform kernel forced to its 256- / 128-register build (development knob BCE_VARIANT)
     u32 cu_count;          // compute units of the device (automatic choice: a launch of <= cu_count workgroups)
+    u32 fuse_tail;         // 1: saturated launches of the split-transform kernel run the tail in their epilogue (BCE_FUSE_TAIL=0 disables)
     u32 I4[4], I4s[4];     // powers of I = psi^(N/2) (primitive 4th root of unity) and Shoup companions
     const uint2* tw_f;  // [N] (psi^brv(i), shoup), index m+i as in the CT forward NTT; the inverse
                         // transform derives psi^-k = -psi^(N-k) from the same table
@@ -66,8 +67,12 @@ size_t blind_rotate_lds_bytes(const DevParams& P);
 
 // acc_out: u32 [n_boot][2][N], COEFFICIENT domain, values in [0, Q)
 // *kernel_id (optional) receives the enum bce_br_kernel value of the kernel that was launched
+// *tail_fused (optional) is set when the launched kernel also ran the tail of EvalBinGate (extract, ModSwitch,
+// KeySwitch, ModSwitch -> pool[out]) in its epilogue; the caller then skips launch_tail().  dbg_lweN / dbg_ks as
+// for launch_tail (used only when the tail is fused).
 hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances,
-                               u32 slot_stride, u32* acc_out, hipStream_t s, int* kernel_id = nullptr);
+                               u32 slot_stride, u32* acc_out, hipStream_t s, int* kernel_id = nullptr,
+                               u32* dbg_lweN = nullptr, u32* dbg_ks = nullptr, bool* tail_fused = nullptr);
 
 // extract + ModSwitch(Q->qKS) + KeySwitch + ModSwitch(qKS->q) -> pool[out]
 // dbg_lweN: u32 [n_boot][N+1] or null; dbg_ks: u32 [n_boot][n+1] or null

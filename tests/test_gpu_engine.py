@@ -502,3 +502,36 @@ def test_encryption_randomness_is_fresh_by_default_and_reproducible_on_request(b
     k.KeyGen()
     s2, _ = k.export_sk()
     assert not np.array_equal(s1, s2)
+
+
+def test_std128_fused_tail_every_stage_equals_separate_tail_and_oracle(std128, bce):
+    """Saturated launches of the split-transform kernel (more workgroups than CUs) run extract + ModSwitch + KeySwitch +
+    ModSwitch in the kernel's epilogue (fused_tail) instead of the k_tail_gather / k_tail_finish kernels.  The same
+    gates evaluated in a small launch (separate tail kernels) and inside a 300-gate launch (fused) must agree at every
+    stage, and with the oracle."""
+    o, c = std128
+    base = [x for x in _gate_cases(o, base=9000) if x[0] in (bce.AND, bce.OR, bce.NAND, bce.NOR)][3:9]
+    nb_small, nb_big = len(base), 300
+    c.pool_reserve(2 * nb_small + nb_big)
+    c.lwe_write(np.arange(2 * nb_small, dtype=np.uint32), np.concatenate([np.stack([ca, cb]) for (_, _, _, ca, cb) in base]))
+    small = [(g, 2 * i, 2 * i + 1, 2 * nb_small + i) for i, (g, _, _, _, _) in enumerate(base)]
+    t0 = c.timing()["fused_tail_launches"]
+    acc_s, lweN_s, ks_s = c.debug_eval_stages(small)
+    out_s = c.lwe_read(np.arange(2 * nb_small, 3 * nb_small, dtype=np.uint32))
+    assert c.timing()["fused_tail_launches"] == t0                      # small launch: separate tail kernels
+    big = [(base[i % nb_small][0], 2 * (i % nb_small), 2 * (i % nb_small) + 1, 2 * nb_small + i) for i in range(nb_big)]
+    acc_b, lweN_b, ks_b = c.debug_eval_stages(big)
+    out_b = c.lwe_read(np.arange(2 * nb_small, 2 * nb_small + nb_big, dtype=np.uint32))
+    assert c.timing()["fused_tail_launches"] == t0 + 1                  # saturated launch: tail in the epilogue
+    for i in range(nb_big):
+        k = i % nb_small
+        assert np.array_equal(acc_b[i], acc_s[k]), "accumulator, gate %d" % i
+        assert np.array_equal(lweN_b[i], lweN_s[k]), "extract + ModSwitch, gate %d" % i
+        assert np.array_equal(ks_b[i], ks_s[k]), "KeySwitch, gate %d" % i
+        assert np.array_equal(out_b[i], out_s[k]), "final ciphertext, gate %d" % i
+    for k, (g, a, b, ca, cb) in enumerate(base[:3]):
+        r_acc = o.blind_rotate(g, o.gate_prep(g, ca, cb))
+        r_lweN = o.extract_modswitch(r_acc)
+        r_ks = o.keyswitch(r_lweN)
+        assert np.array_equal(acc_s[k], r_acc) and np.array_equal(lweN_s[k], r_lweN) and np.array_equal(ks_s[k], r_ks)
+        assert np.array_equal(out_s[k], o.modswitch_final(r_ks)) and o.decrypt(out_s[k]) == _truth(g, a, b)
