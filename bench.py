@@ -284,7 +284,10 @@ def main():
         br_s = dom["ms"] / 1e3
         per_launch = dom["bootstraps"] / max(1, dom["launches"])
         avg_launch_ms = dom["ms"] / max(1, dom["launches"])
-        br_bytes = parts["bsk"] + parts["ct"]             # what the blind-rotation kernel itself reads / writes per bootstrap
+        # saturated launches of the split-transform kernel run the tail (KSK row gather) in their epilogue: the KSK rows are
+        # then bytes of the blind-rotation kernel, and no tail kernel exists
+        fused = tm["fused_tail_launches"] >= tm["blind_rotate_launches"] > 0
+        br_bytes = parts["bsk"] + parts["ct"] + (parts["ksk"] if fused else 0)   # what the dominant kernel itself moves per bootstrap
         achieved = (br_bytes * dom["bootstraps"] / br_s) / 1e9 if br_s > 0 else 0.0
         tail_s = tm["tail_ms"] / 1e3
         tail_achieved = (parts["ksk"] * tm["bootstraps"] / tail_s) / 1e9 if tail_s > 0 else 0.0
@@ -298,23 +301,26 @@ def main():
             "traffic": traffic["hbm_bytes_per_launch"] if traffic and traffic.get("bench_kernel") == dom["kernel"] else None,
             "traffic_source": "profiles/r02_pmc_traffic.json: bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of "
                               "this default command, tools/collect_evidence.sh) -- a committed constant replayed here, NOT measured in this run",
-            "bytes_per_bootstrap": {"blind_rotation (u32 BSK rows + u32 ct in/acc out)": br_bytes, "tail (u16 KSK rows)": parts["ksk"], "total": bpb},
+            "bytes_per_bootstrap": {"bsk_rows_u32": parts["bsk"], "ct_io_u32": parts["ct"], "ksk_rows_u16": parts["ksk"], "total": bpb,
+                                    "billed_to_this_kernel": br_bytes, "tail_fused_into_this_kernel": bool(fused)},
             "algorithmic_bytes_per_launch": br_bytes * per_launch,
             # the key is reused from cache across a batch, so also the compulsory bytes of a launch:
             # the key once + per-bootstrap ciphertext / accumulator I/O
-            "compulsory_bytes_per_launch": bsk_once + parts["ct"] * per_launch,
+            "compulsory_bytes_per_launch": bsk_once + (parts["ct"] + (parts["ksk"] if fused else 0)) * per_launch,
             "bootstraps_per_launch": per_launch,
             "avg_launch_ms": avg_launch_ms,
             "launches": dom["launches"],
             "share_of_blind_rotation_time": dom["ms"] / max(1e-9, tm["blind_rotate_ms"]),
             "other_blind_rotation_kernels": [k for k in tm["by_kernel"] if k is not dom and k["launches"]],
-            "tail": {"kernel": "k_tail_gather + k_tail_finish", "bound": "hbm", "ms_total": tm["tail_ms"],
-                     "avg_launch_ms": tm["tail_ms"] / max(1, tm["blind_rotate_launches"]),
-                     "achieved": tail_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tail_achieved / HBM_PEAK_GBS,
-                     "traffic": (traffic or {}).get("tail_hbm_bytes_per_launch"),
-                     "note": "KSK row gather: algorithmic = N*dKS rows of (n+1) u16 per bootstrap; rows come from the 256 MiB table "
-                             "(Infinity-Cache sized), so the fabric counters see them"},
-            "note": "achieved = algorithmic bytes of the blind-rotation kernel (u32 BSK rows + ct I/O per bootstrap) x bootstraps / its "
+            "tail": ({"kernel": "none: extract + ModSwitch + KeySwitch + ModSwitch run in the epilogue of the blind-rotation kernel (fused_tail)",
+                      "ms_total": tm["tail_ms"]} if fused else
+                     {"kernel": "k_tail_gather + k_tail_finish", "bound": "hbm", "ms_total": tm["tail_ms"],
+                      "avg_launch_ms": tm["tail_ms"] / max(1, tm["blind_rotate_launches"]),
+                      "achieved": tail_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tail_achieved / HBM_PEAK_GBS,
+                      "traffic": (traffic or {}).get("tail_hbm_bytes_per_launch"),
+                      "note": "KSK row gather: algorithmic = N*dKS rows of (n+1) u16 per bootstrap; rows come from the 256 MiB table "
+                              "(Infinity-Cache sized), so the fabric counters see them"}),
+            "note": "achieved = algorithmic bytes of the blind-rotation kernel (u32 BSK rows + ct I/O + the KSK rows of its fused tail, per bootstrap) x bootstraps / its "
                     "time from HIP events on the engine stream.  The 62.8 MiB key is served from L2 / Infinity Cache across the "
                     "batch (compulsory << algorithmic), so this fraction can exceed 1 and does not bind; the binding roof is "
                     "integer-VALU issue: see `valu`",
