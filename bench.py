@@ -192,8 +192,11 @@ def main():
         circ.setInstances(K_total)
         xch = None
         if gates:
+            # boundary ciphertexts: the library's own RCCL all-gather on the engine stream when RCCL is the backend
+            # (falls back, on every rank together, to the torch.distributed callback if RCCL cannot be initialised)
             xch = importlib.import_module("openfhe-boolean-circuit-evaluator_amd.dist").Exchange(
-                circ, 1, encrypted=True, device=torch.device("cuda", local_rank))
+                circ, 1, encrypted=True, device=torch.device("cuda", local_rank),
+                in_library=(backend == "nccl" and os.environ.get("BCE_EXCHANGE", "rccl") == "rccl"))
         rng = np.random.default_rng(12345 + (0 if gates else rank))
         widths = info["n_input_bits"]
         inputs = []
@@ -256,7 +259,9 @@ def main():
             cc.set_encrypt_seed(None)
         circ.close()
         return {"elapsed": elapsed, "total_boot": total_boot, "verified": verified, "tm": tm, "info": info, "relevel": relevel,
-                "exchanges_per_step": st["exchanges"], "exchanged_cts_per_step": xcts, "steps": steps, "t_ready": t_ready}
+                "exchanges_per_step": st["exchanges"], "exchanged_cts_per_step": xcts, "steps": steps, "t_ready": t_ready,
+                "exchange_path": ("in-library ncclAllGather on the engine stream (no host sync)" if (xch is not None and xch.in_library) else
+                                  ("torch.distributed all_gather_into_tensor callback after a stream sync" + (" [in-library RCCL unavailable: %s]" % xch.why if xch is not None and xch.why not in ("", "not requested") else "")) if xch is not None else "none")}
 
     shard_mode = 0 if args.shard == "instances" else 1
     R = run_mode(shard_mode, args.steps, args.warmup, args.relevel)
@@ -374,6 +379,7 @@ def main():
                 "value": G["total_boot"] / G["elapsed"], "unit": "gate-bootstraps/s", "scaling": "strong",
                 "ms_per_step": G["elapsed"] / G["steps"] * 1e3, "steps": G["steps"], "warmup": 1,
                 "exchanges_per_step": G["exchanges_per_step"], "exchanged_cts_per_step": G["exchanged_cts_per_step"],
+                "exchange_path": G["exchange_path"],
                 "outputs_verified": bool(G["verified"]),
             }
             verified = verified and G["verified"]

@@ -120,6 +120,11 @@ int bce_circuit_dump(const bce_circuit*, int what);
 int bce_circuit_set_exchange(bce_circuit*, uint32_t rank, uint32_t world, int shard_mode, bce_allgather_fn fn,
                              void* user, void* host_send, void* host_recv, void* dev_send, void* dev_recv,
                              uint64_t capacity);
+/* After bce_circuit_set_exchange: exchange DEVICE payloads (boundary ciphertexts of shard_mode 1) with the
+ * in-library RCCL all-gather on the engine stream (bce_rccl_init must have been called on the circuit's engine)
+ * instead of the callback -- no host synchronisation and no callback per level.  Host payloads (plaintext bits,
+ * final outputs) keep using the callback.  on = 0 returns to the callback for everything. */
+int bce_circuit_enable_rccl(bce_circuit*, int on);
 /* bytes one rank may contribute in the largest exchange of this circuit/instance count */
 uint64_t bce_circuit_exchange_capacity(const bce_circuit*, uint32_t world, int shard_mode, int encrypted);
 

@@ -176,6 +176,18 @@ uint64_t bce_bytes_per_bootstrap(const bce_ctx*);
  * out[1] = key-switching-key rows (tail gather), out[2] = ciphertext input / output words */
 int bce_bytes_per_bootstrap_parts(const bce_ctx*, uint64_t out[3]);
 
+/* ---- in-library collective (multi-GPU, one process per GPU) ---------------------------------------------
+ * RCCL all-gather issued on the engine's own stream, so that the exchange of boundary ciphertexts between two
+ * dependent frontiers needs neither a host synchronisation nor the host language (bce_circuit_enable_rccl uses
+ * it).  RCCL is dlopen()ed on first use.  Rendezvous: rank 0 calls bce_rccl_unique_id and the host program
+ * delivers the 128 bytes to every rank, each of which then calls bce_rccl_init with its rank. */
+int bce_rccl_unique_id(uint8_t out[128]);
+int bce_rccl_init(bce_ctx*, const uint8_t uid[128], int rank, int world);
+/* every rank contributes `bytes` bytes at dev_send and receives world * bytes at dev_recv, rank-major; asynchronous,
+ * ordered with the engine's kernels */
+int bce_rccl_allgather(bce_ctx*, const void* dev_send, void* dev_recv, uint64_t bytes);
+int bce_rccl_shutdown(bce_ctx*);
+
 /* ---- staged outputs for parity tests ----------------------------------- */
 /* Runs the frontier like bce_eval_gates and also returns the intermediates
  * (any pointer may be NULL): acc = accumulator after blind rotation,

@@ -57,7 +57,8 @@ ENGINE_SYMBOLS = [
     "bce_keygen", "bce_import_keys", "bce_import_keys_file", "bce_export_keys_file", "bce_bsk_words", "bce_ksk_words", "bce_export_sk", "bce_export_bsk",
     "bce_export_ksk", "bce_pool_reserve", "bce_pool_slots", "bce_lwe_write", "bce_lwe_read",
     "bce_encrypt_bits", "bce_set_encrypt_seed", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize",
-    "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_debug_eval_stages", "bce_debug_ntt",
+    "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
+    "bce_rccl_shutdown", "bce_debug_eval_stages", "bce_debug_ntt",
 ]
 
 _lib = None
@@ -112,6 +113,10 @@ def lib():
     L.bce_bytes_per_bootstrap.argtypes = [vp]
     L.bce_bytes_per_bootstrap.restype = u64
     L.bce_bytes_per_bootstrap_parts.argtypes = [vp, C.POINTER(u64)]
+    L.bce_rccl_unique_id.argtypes = [C.c_char_p]
+    L.bce_rccl_init.argtypes = [vp, C.c_char_p, i32, i32]
+    L.bce_rccl_allgather.argtypes = [vp, vp, vp, u64]
+    L.bce_rccl_shutdown.argtypes = [vp]
     L.bce_debug_eval_stages.argtypes = [vp, u32, vp, vp, vp, vp]
     L.bce_debug_ntt.argtypes = [vp, vp, u32, i32]
     _lib = L
@@ -275,6 +280,21 @@ class BinFHEContext:
     def bytes_per_bootstrap(self):
         return int(self._L.bce_bytes_per_bootstrap(self.h))
 
+    # --- in-library RCCL all-gather on the engine stream (multi-GPU exchange without host sync) ---
+    @staticmethod
+    def rccl_unique_id():
+        buf = C.create_string_buffer(128)
+        rc = lib().bce_rccl_unique_id(buf)
+        if rc != OK:
+            raise BceError(rc, "RCCL is not available (bce_rccl_unique_id)")
+        return buf.raw
+
+    def rccl_init(self, uid, rank, world):
+        self._ck(self._L.bce_rccl_init(self.h, bytes(uid), int(rank), int(world)))
+
+    def rccl_allgather(self, dev_send_ptr, dev_recv_ptr, nbytes):
+        self._ck(self._L.bce_rccl_allgather(self.h, C.c_void_p(dev_send_ptr), C.c_void_p(dev_recv_ptr), int(nbytes)))
+
     def bytes_per_bootstrap_parts(self):
         buf = (C.c_uint64 * 3)()
         self._ck(self._L.bce_bytes_per_bootstrap_parts(self.h, buf))
@@ -322,7 +342,7 @@ CIRCUIT_SYMBOLS = [
     "bce_circuit_set_encrypted", "bce_circuit_set_verify", "bce_circuit_get_flags", "bce_circuit_set_batched",
     "bce_circuit_set_encrypt_mode", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
     "bce_circuit_get_output", "bce_circuit_get_buses", "bce_circuit_get_counts", "bce_circuit_get_stats", "bce_circuit_dump",
-    "bce_circuit_set_exchange", "bce_circuit_exchange_capacity", "bce_assemble_bristol", "bce_pool_gather",
+    "bce_circuit_set_exchange", "bce_circuit_enable_rccl", "bce_circuit_exchange_capacity", "bce_assemble_bristol", "bce_pool_gather",
     "bce_pool_scatter",
 ]
 
@@ -355,6 +375,7 @@ def _bind_circuit():
     L.bce_circuit_get_counts.argtypes = [vp, C.POINTER(u32 * 6)]
     L.bce_circuit_get_stats.argtypes = [vp, C.POINTER(CircuitStats)]
     L.bce_circuit_set_exchange.argtypes = [vp, u32, u32, i32, ALLGATHER_FN, vp, vp, vp, vp, vp, u64]
+    L.bce_circuit_enable_rccl.argtypes = [vp, i32]
     L.bce_circuit_exchange_capacity.argtypes = [vp, u32, i32, i32]
     L.bce_circuit_exchange_capacity.restype = u64
     L.bce_assemble_bristol.argtypes = [C.c_char_p, i32, i32, i32, C.c_char_p, C.c_char_p, u32]
@@ -529,6 +550,10 @@ class Circuit:
 
     def dumpGateCount(self):
         self._ck(self._L.bce_circuit_dump(self.h, 2))
+
+    def enable_rccl(self, on=True):
+        """device payloads of the exchange through the in-library RCCL all-gather (after cc.rccl_init)"""
+        self._ck(self._L.bce_circuit_enable_rccl(self.h, int(on)))
 
     def exchange_capacity(self, world, shard_mode, encrypted):
         return int(self._L.bce_circuit_exchange_capacity(self.h, world, shard_mode, int(encrypted)))

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libbce_amd.so")
 OBJ = os.path.join(HERE, "_obj")
 
-SOURCES = ["kernels.hip", "kernels64.hip", "keygen.hip", "engine.cpp", "keyfile.cpp", "bristol.cpp", "circuit.cpp", "circuit_capi.cpp"]
+SOURCES = ["kernels.hip", "kernels64.hip", "keygen.hip", "engine.cpp", "keyfile.cpp", "rccl_xchg.cpp", "bristol.cpp", "circuit.cpp", "circuit_capi.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-Wall",
          "-Wno-unused-result", "-Wno-unused-value"]
 FLAGS += os.environ.get("BCE_EXTRA_FLAGS", "").split()  # development builds only (e.g. -DBCE_PHASE_PROF)
@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s" % s)
         if verbose and out:
             sys.stderr.write(out.decode())
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs + ["-lpthread"]
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs + ["-lpthread", "-ldl"]
     subprocess.check_call(cmd)
     return OUT
 

@@ -570,8 +570,13 @@ void Circuit::exchangeLevel(size_t level) {
         std::vector<uint32_t> slots;
         for (unsigned i = 0; i < K; ++i) for (size_t k = 0; k < widest; ++k) slots.push_back(i * stride_ + (uint32_t)(k < mine.size() ? mine[k] : (mine.empty() ? 0 : mine[0])));
         ck(bce_pool_gather(cc, slots.data(), (uint32_t)slots.size(), dev_send_), "exchange(gather)");
-        ck(bce_synchronize(cc), "exchange(sync)");
-        if (xfn_(xuser_, bytes, 1) != 0) throw std::runtime_error("exchange: allgather callback failed");
+        if (rccl_) {
+            // stream-ordered: pack kernel -> ncclAllGather -> scatter kernels, all on the engine's stream
+            ck(bce_rccl_allgather(cc, dev_send_, dev_recv_, bytes), "exchange(RCCL all-gather)");
+        } else {
+            ck(bce_synchronize(cc), "exchange(sync)");
+            if (xfn_(xuser_, bytes, 1) != 0) throw std::runtime_error("exchange: allgather callback failed");
+        }
         for (uint32_t r = 0; r < world_; ++r) {
             if (r == rank_) continue;
             const auto& theirs = xwires_[level][r];

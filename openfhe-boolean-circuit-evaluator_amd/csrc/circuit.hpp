@@ -138,6 +138,7 @@ public:
     void setExchange(uint32_t rank, uint32_t world, int shard_mode, bce_allgather_fn fn, void* user, void* host_send,
                      void* host_recv, void* dev_send, void* dev_recv, uint64_t capacity);
     uint64_t exchangeCapacity(uint32_t world, int shard_mode, bool encrypted) const;
+    void enableRccl(bool on) { rccl_ = on; }
     bce_ctx* engine() const { return cc; }
 
 private:
@@ -193,6 +194,7 @@ private:
     void* xuser_ = nullptr;
     void *host_send_ = nullptr, *host_recv_ = nullptr, *dev_send_ = nullptr, *dev_recv_ = nullptr;
     uint64_t xcap_ = 0;
+    bool rccl_ = false;  // device payloads through bce_rccl_allgather on the engine stream (no host sync, no callback)
     std::vector<std::vector<uint8_t>> owner_;                 // [level][k] owner rank of levels_[level].gates[k]
     std::vector<std::vector<std::vector<int>>> xwires_;       // [level][rank] -> wires that rank must publish
 

@@ -136,6 +136,7 @@ int bce_circuit_set_exchange(bce_circuit* h, uint32_t rank, uint32_t world, int 
                              void* host_send, void* host_recv, void* dev_send, void* dev_recv, uint64_t capacity) {
     return guarded(h, [&] { h->c.setExchange(rank, world, shard_mode, fn, user, host_send, host_recv, dev_send, dev_recv, capacity); });
 }
+int bce_circuit_enable_rccl(bce_circuit* h, int on) { return guarded(h, [&] { h->c.enableRccl(on != 0); }); }
 uint64_t bce_circuit_exchange_capacity(const bce_circuit* h, uint32_t world, int shard_mode, int encrypted) {
     return h ? h->c.exchangeCapacity(world, shard_mode, encrypted != 0) : 0;
 }

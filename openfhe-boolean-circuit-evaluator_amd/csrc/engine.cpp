@@ -96,6 +96,7 @@ struct bce_ctx {
     uint8_t enc_seed[32] = {0};
     bool enc_seed_ok = false, enc_deterministic = false;
     uint64_t enc_counter = 0;
+    void* rccl_comm = nullptr;   // ncclComm_t of the in-library all-gather (rccl_xchg.cpp), if enabled
     // pool
     u32* d_pool = nullptr;
     u32 pool_slots = 0;
@@ -598,6 +599,7 @@ void bce_ctx_destroy(bce_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->rccl_comm) bce_rccl_shutdown(c);
     drain_timing(c);
     for (auto& p : c->free_events) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (int i = 0; i < bce_ctx::kRing; ++i) {
@@ -609,6 +611,10 @@ void bce_ctx_destroy(bce_ctx* c) {
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
+
+hipStream_t bce_internal_stream(bce_ctx* c) { return c->stream; }
+void** bce_internal_comm_slot(bce_ctx* c) { return &c->rccl_comm; }
+int bce_rccl_shutdown(bce_ctx* c);
 
 int bce_set_error(bce_ctx* c, int code, const char* msg) {  // for the other translation units of the library (keyfile.cpp)
     if (c) c->err = msg ? msg : "";

@@ -10,7 +10,13 @@ import torch.distributed as dist
 
 
 class Exchange:
-    def __init__(self, circuit, shard_mode, encrypted, device=None, group=None):
+    """in_library=True (and backend nccl): device payloads go through the library's own RCCL all-gather on the engine
+    stream (bce_rccl_init / bce_circuit_enable_rccl) -- no host synchronisation and no Python in the per-level loop;
+    this class then only carries host payloads (plaintext bits, final outputs) and the rendezvous of the unique id.
+    `self.in_library` tells which path is active (False with a reason in `self.why` when RCCL could not be set up:
+    every rank then uses the callback path, by agreement)."""
+
+    def __init__(self, circuit, shard_mode, encrypted, device=None, group=None, in_library=False):
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.group = group
@@ -25,10 +31,37 @@ class Exchange:
             self.dev_send = torch.zeros(cap, dtype=torch.uint8, device=device)
             self.dev_recv = torch.zeros(cap * self.world, dtype=torch.uint8, device=device)
         self.calls = 0
+        self.in_library, self.why = False, "not requested"
         circuit.set_exchange(self.rank, self.world, shard_mode, self._allgather,
                              self.host_send.data_ptr(), self.host_recv.data_ptr(),
                              self.dev_send.data_ptr() if device is not None else None,
                              self.dev_recv.data_ptr() if device is not None else None, cap)
+        if in_library and device is not None and encrypted:
+            self._setup_in_library(circuit)
+
+    def _setup_in_library(self, circuit):
+        ok, why = 1, ""
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        uid = torch.zeros(128, dtype=torch.uint8, device=self.device if on_gpu else "cpu")
+        try:
+            if self.rank == 0:
+                raw = circuit.cc.rccl_unique_id()
+                uid.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        except Exception as e:
+            ok, why = 0, repr(e)
+        dist.broadcast(uid, 0, group=self.group)
+        if ok:
+            try:
+                circuit.cc.rccl_init(bytes(uid.cpu().numpy().tobytes()), self.rank, self.world)
+            except Exception as e:
+                ok, why = 0, repr(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)      # all ranks or none
+        if int(flag.item()) == 1:
+            circuit.enable_rccl(True)
+            self.in_library, self.why = True, ""
+        else:
+            self.why = why or "another rank could not initialise RCCL"
 
     def _allgather(self, nbytes, on_device):
         try:

@@ -77,3 +77,35 @@ def test_encrypted_gate_sharding_exchanges_boundary_ciphertexts():
         assert exchanges > 0 and cts > 0
         total += boots
     assert total == 310                              # every bootstrap ran on exactly one rank
+
+
+def test_in_library_rccl_allgather_world_of_one():
+    """The library's own RCCL all-gather (rccl_xchg.cpp: dlopen, ncclCommInitRank, ncclAllGather on the engine
+    stream).  A one-GPU box can only form a world of one (RCCL refuses two ranks on one device), which still
+    exercises the loader, the communicator, the stream plumbing and the ordering with the engine's kernels:
+    pool rows packed by k_pool_pack -> all-gather -> read back, without any synchronisation in between."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    bce = importlib.import_module("openfhe-boolean-circuit-evaluator_amd")
+    cc = bce.BinFHEContext(bce.TOY, bce.GINX, device=0)
+    cc.KeyGen(11)
+    cc.pool_reserve(8)
+    cc.Encrypt([1, 0, 1, 1], [0, 1, 2, 3])
+    want = cc.lwe_read([0, 1, 2, 3]).astype(np.uint32)
+    uid = cc.rccl_unique_id()
+    assert len(uid) == 128
+    cc.rccl_init(uid, 0, 1)
+    W = cc.n + 1
+    send = torch.zeros(4 * W, dtype=torch.int32, device="cuda:0")
+    recv = torch.zeros(4 * W, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    slots = np.arange(4, dtype=np.uint32)
+    L = bce.lib()
+    assert L.bce_pool_gather(cc.h, slots.ctypes.data, 4, send.data_ptr()) == 0      # engine stream, asynchronous
+    cc.rccl_allgather(send.data_ptr(), recv.data_ptr(), 4 * W * 4)                    # same stream, no sync before
+    cc.synchronize()
+    got = recv.cpu().numpy().view(np.uint32).reshape(4, W)
+    assert np.array_equal(got, want)
+    with pytest.raises(bce.BceError):
+        bce.BinFHEContext(bce.TOY, bce.GINX, device=0).rccl_allgather(send.data_ptr(), recv.data_ptr(), 16)   # no communicator
