@@ -101,7 +101,7 @@ def test_in_library_rccl_allgather_world_of_one():
     recv = torch.zeros(4 * W, dtype=torch.int32, device="cuda:0")
     torch.cuda.synchronize()
     slots = np.arange(4, dtype=np.uint32)
-    L = bce.lib()
+    L = bce._bind_circuit()                                                           # sets the argtypes of bce_pool_gather
     assert L.bce_pool_gather(cc.h, slots.ctypes.data, 4, send.data_ptr()) == 0      # engine stream, asynchronous
     cc.rccl_allgather(send.data_ptr(), recv.data_ptr(), 4 * W * 4)                    # same stream, no sync before
     cc.synchronize()
