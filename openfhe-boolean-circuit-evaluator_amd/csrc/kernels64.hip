@@ -678,6 +678,66 @@ __device__ __forceinline__ void forward_phase_balanced(double* dct, int NP, Tw t
     }
 }
 
+// One HALF of a forward transform (stages on bits 7..0; bits 10, 9, 8 were applied by the producer) by one wave:
+// 128 virtual lanes per polynomial, v = half * 64 + lane, 16 coefficients per lane (bits 7..4, then 3..0), one
+// workgroup barrier between the two passes (the two halves exchange data), executed by every wave of the workgroup.
+template <int LOGN>
+__device__ __forceinline__ void forward_half(double* poly, Tw twa, u32 v, double Q) {
+    static_assert(LOGN == 11, "laid out for N = 2048");
+    double x[16];
+        {   // pass A: registers = position bits 7..4; v[3:0] = p[3:0], v[6:4] = p[10:8]
+            const u32 hi = v >> 4, base = (hi << 8) | (v & 15u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = poly[phys(base | ((u32)r << 4))];
+#pragma unroll
+            for (int B = 7; B >= 4; --B) {           // stage on bit B = register bit B - 4; twiddle tw[m + (p >> (B+1))]
+                const int rb = B - 4;
+                const u32 m = 1u << (10 - B);
+                const double2* tw = twa.l;  // m <= 64: LDS mirror
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (r & (1 << rb)) continue;
+                    const double2 w = tw[m + ((hi << (7 - B)) | (u32)(r >> (rb + 1)))];
+                    const double X = x[r];
+                    const double T = modmul_q(x[r | (1 << rb)], w.x, w.y, Q);
+                    x[r] = X + T;
+                    x[r | (1 << rb)] = X - T;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) poly[phys(base | ((u32)r << 4))] = x[r];
+        }
+        block_sync_lds();
+        {   // pass B: registers = position bits 3..0; v = p[10:4]
+            const u32 base = v << 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = poly[phys(base | (u32)r)];
+#pragma unroll
+            for (int B = 3; B >= 0; --B) {
+                const u32 m = 1u << (10 - B);
+                const double2* tw = (B == 0) ? twa.g : twa.l;  // only the block of the last stage (m = 1024) is global
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (r & (1 << B)) continue;
+                    const double2 w = tw[m + ((v << (3 - B)) | (u32)(r >> (B + 1)))];
+                    const double X = x[r];
+                    const double T = modmul_q(x[r | (1 << B)], w.x, w.y, Q);
+                    x[r] = X + T;
+                    x[r | (1 << B)] = X - T;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) poly[phys(base | (u32)r)] = x[r];
+        }
+}
+// Forward phase of the 16-wave (N = 2048) workgroup: the 6 digit polynomials as 12 half-transforms on waves 0..11
+// (three per SIMD); waves 12..15 only take part in the barrier.
+template <int LOGN>
+__device__ __forceinline__ void forward_phase_halves(double* dct, int NP, Tw twa, u32 wave, u32 lane, double Q) {
+    if (wave < 12) forward_half<LOGN>(dct + (wave % 6u) * NP, twa, (wave / 6u) * 64u + lane, Q);
+    else block_sync_lds();
+}
+
 // inverse NTT by one wave; |src| <= 0.6 Q bit-reversed; coefficient j = (r << 6) | lane in x[r], |x| <= 0.57 Q
 template <int LOGN>
 __device__ __forceinline__ void ntt_inverse_wave(const double* src, double* tmp, Tw tw, u32 lane, double Q,
@@ -810,13 +870,31 @@ __device__ __forceinline__ void split_inverse11(const double* src, double* bufA,
 
 // SPLIT (N = 2048 only): 512-thread workgroup, inverse transforms on all 8 waves (split_inverse11), forward
 // transforms on waves 0..R-1, 4 MAC items per thread.
-template <int LOGN, int DG, bool AP, bool SPLIT = false, u32 NBUF_ = (AP ? 3 : 2), u32 NPRE_ = (AP ? 2 : 1)>
-__global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
+// W16 (with SPLIT): 1024-thread workgroup = 4 waves per SIMD on the one workgroup a CU's LDS holds.  The inverse
+// transforms stay on waves 0..7 (8 coefficients per thread is what keeps them at 4 passes); the forward phase runs as
+// 12 half-transforms on waves 0..11 and the MAC as 2 items per thread on all 16 waves, so that the LDS traffic of one
+// wave (twiddles + coefficients: ~6 k cycles of the phase, profiles/r02_phase_std192_ap.log) overlaps with the
+// arithmetic of three others instead of one.  128-register budget: key rows one (GINX) / two (AP) items deep.
+// key-row pipeline depth of the 16-wave build (development knobs, tools/w16_sweep.sh).  Measured on one MI355X, STD192,
+// 256 bootstraps per launch (profiles/r02_w16_sweep.log): 8 waves 28.1 ms (AP) / 17.0 ms (GINX); 16 waves with one item
+// in flight and nothing requested before the transforms 25.9 / 18.5 ms; every deeper pipeline spills 33..81 registers of
+// the 128 a 1024-thread workgroup leaves each thread and is slower than the 8-wave build.
+#ifndef BCE_W16_NBUF_AP
+#define BCE_W16_NBUF_AP 1
+#define BCE_W16_NPRE_AP 0
+#define BCE_W16_NBUF_GINX 1
+#define BCE_W16_NPRE_GINX 0
+#endif
+template <int LOGN, int DG, bool AP, bool SPLIT = false, bool W16 = false,
+          u32 NBUF_ = (W16 ? (AP ? BCE_W16_NBUF_AP : BCE_W16_NBUF_GINX) : (AP ? 3 : 2)),
+          u32 NPRE_ = (W16 ? (AP ? BCE_W16_NPRE_AP : BCE_W16_NPRE_GINX) : (AP ? 2 : 1))>
+__global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind_rotate64d(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
                                                                u32 slot_stride, u64* __restrict__ acc_out) {
     using C = Cfg<LOGN>;
     constexpr int N = C::N, NP = C::NP, E = C::E;
-    constexpr u32 R = 2 * DG, T = SPLIT ? 512 : 64 * R;
+    constexpr u32 R = 2 * DG, T = W16 ? 1024 : (SPLIT ? 512 : 64 * R);
     static_assert(!SPLIT || (LOGN == 11 && R <= 8 && R >= 4), "split inverse transform: N = 2048");
+    static_assert(!W16 || (SPLIT && R == 6), "16-wave variant: N = 2048, three gadget digits");
     extern __shared__ __align__(16) double smemd[];
     double* acc = smemd;          // [2][NP] evaluation form, |value| <= 0.6 Q
     double* dct = acc + 2 * NP;   // [R][NP]
@@ -825,7 +903,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
     // LDS mirror of the first 1024 twiddle entries (8-wave kernel only: 16 KiB of the 20 KiB left next to the polynomials)
     double2* twl = reinterpret_cast<double2*>(av + ((P.n + 1 + 3) & ~3u));
     if constexpr (SPLIT)
-        for (u32 i = threadIdx.x; i < 1024u; i += 512u) twl[i] = tw[i];
+        for (u32 i = threadIdx.x; i < 1024u; i += T) twl[i] = tw[i];
     const Tw twa{tw, twl};
 
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -927,7 +1005,10 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
         };
         if constexpr (NPRE >= 1) request(std::integral_constant<u32, 0>{});
         if constexpr (NPRE >= 2) request(std::integral_constant<u32, 1>{});
-        if constexpr (SPLIT) {
+        if (W16 && tid_v >= 512u) {
+            // waves 8..15 have no share of the inverse transforms: they only keep the barrier count
+            block_sync_lds(); block_sync_lds(); block_sync_lds(); block_sync_lds();
+        } else if constexpr (SPLIT) {
             const u32 c = wave >> 2, t = tid_v & 255u;
             double x[8];
             // exchange buffers live in dct rows 0..3 (dead until the digits are written)
@@ -995,7 +1076,9 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
         BCE_PROF_MARK(0);
         block_sync_lds();
         BCE_PROF_MARK(1);
-        if constexpr (SPLIT) {
+        if constexpr (W16) {
+            forward_phase_halves<LOGN>(dct, NP, twa, wave, lane_v, Q);
+        } else if constexpr (SPLIT) {
             forward_phase_balanced<LOGN>(dct, NP, twa, wave, lane_v, Q);
         } else {
             ntt_forward_wave<LOGN>(dct + wave * NP, Tw{tw, nullptr}, lane_v, Q);
@@ -1026,6 +1109,9 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
                         sn[0] += modmul(d.x, kn.x, invQ, Q);
                         sn[1] += modmul(d.y, kn.y, invQ, Q);
                     }
+                    // 128-register build: keep the rows in program order (interleaving all of them for instruction-level
+                    // parallelism needs ~70 temporaries; four waves per SIMD provide the parallelism instead)
+                    if constexpr (W16) __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 request(std::integral_constant<u32, k + NBUF>{});
@@ -1059,7 +1145,9 @@ __global__ __launch_bounds__(SPLIT ? 512 : 128 * DG) void k_blind_rotate64d(DevP
         block_sync_lds();
         BCE_PROF_MARK(5);
     }
-    if constexpr (SPLIT) {
+    if (W16 && tid >= 512u) {
+        block_sync_lds(); block_sync_lds(); block_sync_lds();
+    } else if constexpr (SPLIT) {
         const u32 c = wave >> 2, t = tid & 255u;
         double x[8];
         split_inverse11(acc + c * NP, dct + c * NP, dct + (2 + c) * NP, twa, t, Q, x);
@@ -1123,7 +1211,19 @@ hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32
         switch (P.logN) {
             case 9: kern = ap ? wd::k_blind_rotate64d<9, 3, true> : wd::k_blind_rotate64d<9, 3, false>; break;
             case 10: kern = ap ? wd::k_blind_rotate64d<10, 3, true> : wd::k_blind_rotate64d<10, 3, false>; break;
-            case 11: kern = ap ? wd::k_blind_rotate64d<11, 3, true, true> : wd::k_blind_rotate64d<11, 3, false, true>; threads = 512; break;
+            case 11: {
+                // AP (BASELINE config 5): the 16-wave build (-8 % per launch); GINX keeps the 8-wave build, whose two-key MAC
+                // items do not fit the 128-register budget (16 waves: +9 %).  BCE_VARIANT=2 / 3 force 8 / 16 waves.
+                const bool w16 = P.variant == 3 || (P.variant != 2 && ap);
+                if (w16) {
+                    kern = ap ? wd::k_blind_rotate64d<11, 3, true, true, true> : wd::k_blind_rotate64d<11, 3, false, true, true>;
+                    threads = 1024;
+                } else {
+                    kern = ap ? wd::k_blind_rotate64d<11, 3, true, true> : wd::k_blind_rotate64d<11, 3, false, true>;
+                    threads = 512;
+                }
+                break;
+            }
             default: break;
         }
     } else if (P.fp64 && P.dG == 4 && P.logN == 9) {

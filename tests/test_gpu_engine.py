@@ -378,6 +378,10 @@ def test_q64_custom_context_bit_exact_stages(bce, orc, method, arith, dg, N, mon
     N = 2048 is the ring of BASELINE config 5 (STD192): the doubles kernel runs there as its 512-thread SPLIT
     instantiation (inverse transforms on 8 waves, LDS twiddle mirror), which no smaller ring reaches."""
     monkeypatch.setenv("BCE_FP64", "1" if arith == "fp64" else "0")
+    if N == 2048 and arith == "fp64":
+        # N = 2048 doubles kernel: 8-wave build (GINX default) and 16-wave build (AP default); force the OTHER one for the
+        # second half of the gate cases below so that all four (method, build) pairs are compared with the oracle
+        monkeypatch.setenv("BCE_VARIANT", "0")
     params = _custom64(orc, 13 if dg == 3 else 10, N)
     o = orc.Oracle(method=getattr(orc, method), custom=params)
     o.keygen(31337)
@@ -401,6 +405,17 @@ def test_q64_custom_context_bit_exact_stages(bce, orc, method, arith, dg, N, mon
     descs = [(g, 2 * i, 2 * i + 1, 2 * nb + i) for i, (g, _, _, _, _) in enumerate(cases)]
     acc, lweN, ks = c.debug_eval_stages(descs)
     out = c.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32))
+    if N == 2048 and arith == "fp64":
+        # the other build of the N = 2048 kernel (8 <-> 16 waves) on a context of its own: identical outputs
+        monkeypatch.setenv("BCE_VARIANT", "2" if method == "AP" else "3")
+        c2 = bce.BinFHEContext(method=getattr(bce, method), custom=params)
+        c2.import_keys(o.sk(), o.z(), o.bsk(), o.ksk())
+        c2.pool_reserve(3 * nb)
+        c2.lwe_write(np.arange(2 * nb, dtype=np.uint32), np.concatenate([np.stack([ca, cb]) for (_, _, _, ca, cb) in cases]))
+        acc2, lweN2, ks2 = c2.debug_eval_stages(descs)
+        assert np.array_equal(acc2, acc) and np.array_equal(lweN2, lweN) and np.array_equal(ks2, ks)
+        assert np.array_equal(c2.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32)), out)
+        c2.close()
     for i, (g, a, b, ca, cb) in enumerate(cases):
         r_acc = o.blind_rotate(g, o.gate_prep(g, ca, cb))
         assert np.array_equal(acc[i], r_acc), "64-bit accumulator differs, case %d" % i
