@@ -978,7 +978,10 @@ __device__ __forceinline__ void fused_tail(const DevParams& P, const u32* coef, 
 #pragma unroll
         for (u32 e = 0; e < VW; ++e) tot[e] = 0;
         const u32 CH = P.ks_chunk;                // rows whose elements can be summed in 32 bits
-        constexpr u32 U = 8;                      // rows in flight per lane
+#ifndef BCE_FUSED_U
+#define BCE_FUSED_U 8
+#endif
+        constexpr u32 U = BCE_FUSED_U;            // rows in flight per lane
         u32 r = slice;
         while (r < LR) {
             u32 run[VW];

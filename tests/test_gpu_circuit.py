@@ -270,13 +270,25 @@ def test_relevelled_schedule_same_ciphertexts_fewer_launches(bce, toy_cc, std_cc
     assert np.array_equal(lvl[xor_regs], rel[xor_regs])
     assert np.array_equal(lvl[26], rel[26])                  # R26 = NOT(R25), read by Out1
     assert c.stats()["sublaunches"] < n_lvl
+    # AES-expanded at STD128_OPT (bench.py's workload and schedule): the same input ciphertexts evaluated by gate level
+    # (the reference's Clock rounds) and by bootstrap depth must leave IDENTICAL ciphertexts in every bootstrapped register
     m = bce.Circuit(std_cc)
     m.ReadBristol(os.path.join(CIRCUITS, "AES-expanded.txt"))
-    m.setRelevel(True)
     v = [x for x in kat.AES_VECTORS if x["circuit"] == "AES-expanded"][0]
-    assert _enc_run(m, kat.aes_case(v)[0]) == kat.aes_case(v)[1]
+    m.Reset(); m.setEncrypted(True); m.SetInput(kat.aes_case(v)[0])
+    assert m.Clock()[0] == kat.aes_case(v)[1]
+    assert m.stats()["sublaunches"] == 496
+    lines = [l.split() for l in open(os.path.join(CIRCUITS, "AES-expanded.txt")) if l.strip()]
+    n_in = int(lines[1][0]) + int(lines[1][1])
+    boot_regs = np.array([n_in + gi for gi, t in enumerate(lines[2:]) if t[-1] in ("AND", "XOR")], dtype=np.uint32)
+    assert boot_regs.size == 20325 + 5440
+    by_level = std_cc.lwe_read(boot_regs)
+    m.setRelevel(True)
+    m.Rearm()
+    assert m.Clock()[0] == kat.aes_case(v)[1]
     st = m.stats()
     assert st["bootstraps"] == 66415 and st["sublaunches"] == 416 + 0 and st["levels"] == 416
+    assert np.array_equal(std_cc.lwe_read(boot_regs), by_level), "re-levelled AES registers differ from the gate-level schedule"
 
 
 def test_ieee754_circuits_encrypted_std128(bce, std_cc):

@@ -23,7 +23,7 @@ CONFIGS = [
     ("4 sha256 (new format) STD128_OPT GINX", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
     ("4r sha256 (new format) STD128_OPT GINX bootstrap-depth schedule", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
     ("5 adder_64bit STD192 AP", "adder_64bit.txt", "old", "STD192", "AP", [64]),
-    ("5b AES-expanded STD192 AP", "AES-expanded.txt", "old", "STD192", "AP", [2]),
+    ("5b AES-expanded STD192 AP", "AES-expanded.txt", "old", "STD192", "AP", [2, 8]),
 ]
 
 
