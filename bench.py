@@ -364,7 +364,7 @@ def main():
                 "schedule": "bootstrap-depth levels (NOTs folded, identical ciphertexts)" if R["relevel"] else "gate levels (reference Clock rounds)",
                 "xor": "XOR_FAST (opt-in, 1 bootstrap)" if args.xor_fast else "NOT,NOT,AND,AND,OR (reference, 3 bootstraps)",
                 "bootstraps_per_step": int(total_boot / args.steps),
-                "outputs_verified": bool(verified), "setup_s": round(setup_s, 2), "keygen_s": round(keygen_s, 2),
+                "outputs_verified": bool(verified), "setup_s": round(setup_s, 2), "keygen_s": round(keygen_s, 3),
                 "host_share_of_step": round(1.0 - (tm["blind_rotate_ms"] + tm["tail_ms"]) / (elapsed * 1e3), 4),
                 "exchanges_per_step": R["exchanges_per_step"], "exchanged_cts_per_step": R["exchanged_cts_per_step"],
                 "collective": "none in the timed region (independent input blocks per rank)" if shard_mode == 0 else
