@@ -17,7 +17,7 @@ import json, sys
 raw = json.load(open(sys.argv[1]))
 br = next(k for k in raw if "blind_rotate" in k)
 tails = {k: v for k, v in raw.items() if "k_tail" in k}
-label = {"void bce::k_blind_rotate_lat<4, 4, false>": "k_blind_rotate_lat<4,4> (split transform, 2 workgroups/CU)"}.get(br, br)
+label = "k_blind_rotate_lat<4,4> (split transform, 2 workgroups/CU)" if br.startswith("void bce::k_blind_rotate_lat<4, 4, false") else br
 out = {"kernel": br, "bench_kernel": label,
        "workload": "AES-expanded.txt STD128_OPT GINX instances_per_gpu=32, bootstrap-depth schedule (bench.py default), 1 step",
        "instances_per_gpu": 32, "relevel": True,
