@@ -342,6 +342,7 @@ def main():
                             "source": "profiles/r02_valu_model.json (SQ_INSTS_VALU pass + instruction mix of the ISA + measured issue "
                                       "costs; committed constants, the launch time is this run's)"}
             roof["frac_valu"] = roof["valu"]["frac"]
+            roof["binding"] = {"roof": "integer VALU issue (see `valu`); the HBM fraction above prices bytes the caches serve", "frac": roof["valu"]["frac"]}
         out = {
             "metric": METRIC,
             "value": total_boot / elapsed,
