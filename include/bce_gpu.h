@@ -181,6 +181,7 @@ int bce_bytes_per_bootstrap_parts(const bce_ctx*, uint64_t out[3]);
  * dependent frontiers needs neither a host synchronisation nor the host language (bce_circuit_enable_rccl uses
  * it).  RCCL is dlopen()ed on first use.  Rendezvous: rank 0 calls bce_rccl_unique_id and the host program
  * delivers the 128 bytes to every rank, each of which then calls bce_rccl_init with its rank. */
+int bce_rccl_available(void);   /* 1 when the RCCL library and the entry points used here could be loaded */
 int bce_rccl_unique_id(uint8_t out[128]);
 int bce_rccl_init(bce_ctx*, const uint8_t uid[128], int rank, int world);
 /* every rank contributes `bytes` bytes at dev_send and receives world * bytes at dev_recv, rank-major; asynchronous,

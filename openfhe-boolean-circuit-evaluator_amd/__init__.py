@@ -57,7 +57,7 @@ ENGINE_SYMBOLS = [
     "bce_keygen", "bce_import_keys", "bce_import_keys_file", "bce_export_keys_file", "bce_bsk_words", "bce_ksk_words", "bce_export_sk", "bce_export_bsk",
     "bce_export_ksk", "bce_pool_reserve", "bce_pool_slots", "bce_lwe_write", "bce_lwe_read",
     "bce_encrypt_bits", "bce_set_encrypt_seed", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize",
-    "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
+    "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_rccl_available", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
     "bce_rccl_shutdown", "bce_debug_eval_stages", "bce_debug_ntt",
 ]
 
@@ -281,6 +281,10 @@ class BinFHEContext:
         return int(self._L.bce_bytes_per_bootstrap(self.h))
 
     # --- in-library RCCL all-gather on the engine stream (multi-GPU exchange without host sync) ---
+    @staticmethod
+    def rccl_available():
+        return bool(lib().bce_rccl_available())
+
     @staticmethod
     def rccl_unique_id():
         buf = C.create_string_buffer(128)

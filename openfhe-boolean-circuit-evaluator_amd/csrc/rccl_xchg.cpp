@@ -74,6 +74,8 @@ int fail_nccl(bce_ctx* c, const char* what, int rc) {
 
 extern "C" {
 
+int bce_rccl_available(void) { return rccl().handle ? 1 : 0; }
+
 int bce_rccl_unique_id(uint8_t out[128]) {
     if (!out) return BCE_ERR_ARG;
     Rccl& r = rccl();

@@ -40,28 +40,39 @@ class Exchange:
             self._setup_in_library(circuit)
 
     def _setup_in_library(self, circuit):
-        ok, why = 1, ""
+        """Every step that could leave the ranks disagreeing is agreed on first (all-reduce of a flag), so that either
+        ALL ranks enter ncclCommInitRank or none does."""
         on_gpu = dist.get_backend(self.group) == "nccl"
-        uid = torch.zeros(128, dtype=torch.uint8, device=self.device if on_gpu else "cpu")
-        try:
-            if self.rank == 0:
-                raw = circuit.cc.rccl_unique_id()
-                uid.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
-        except Exception as e:
-            ok, why = 0, repr(e)
-        dist.broadcast(uid, 0, group=self.group)
-        if ok:
+        dev = self.device if on_gpu else "cpu"
+
+        def all_ok(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return int(flag.item()) == 1
+
+        if not all_ok(circuit.cc.rccl_available()):
+            self.why = "RCCL library not loadable on every rank"
+            return
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        ok = True
+        if self.rank == 0:
             try:
-                circuit.cc.rccl_init(bytes(uid.cpu().numpy().tobytes()), self.rank, self.world)
+                uid.copy_(torch.frombuffer(bytearray(circuit.cc.rccl_unique_id()), dtype=torch.uint8))
             except Exception as e:
-                ok, why = 0, repr(e)
-        flag = torch.tensor([ok], dtype=torch.int32, device=self.device if on_gpu else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)      # all ranks or none
-        if int(flag.item()) == 1:
+                ok, self.why = False, repr(e)
+        if not all_ok(ok):
+            self.why = self.why or "rank 0 could not obtain an RCCL unique id"
+            return
+        dist.broadcast(uid, 0, group=self.group)
+        try:
+            circuit.cc.rccl_init(bytes(uid.cpu().numpy().tobytes()), self.rank, self.world)   # collective: all ranks are here
+        except Exception as e:
+            ok, self.why = False, repr(e)
+        if all_ok(ok):
             circuit.enable_rccl(True)
             self.in_library, self.why = True, ""
         else:
-            self.why = why or "another rank could not initialise RCCL"
+            self.why = self.why or "another rank could not initialise RCCL"
 
     def _allgather(self, nbytes, on_device):
         try:
