@@ -165,12 +165,6 @@ int bce_eval_gates(bce_ctx*, uint32_t n_desc, const bce_gate_desc* descs);
 int bce_eval_gates_strided(bce_ctx*, uint32_t n_desc, const bce_gate_desc* descs, uint32_t instances,
                            uint32_t slot_stride);
 int bce_synchronize(bce_ctx*);
-/* Lanes (1..4, default 1).  With L > 1 a strided call over >= L instances is split into L contiguous groups of
- * instances, each evaluated on a HIP stream of its own: the instances of a lock-step run never depend on each other,
- * so the groups drift apart and their launches overlap -- a frontier too narrow to fill the GPU (deep circuits at
- * moderate K) no longer leaves it half-empty between two dependent launches.  Results are identical; per-kernel
- * timings of overlapping launches (bce_timing) then add up to more than the wall time. */
-int bce_set_lanes(bce_ctx*, uint32_t lanes);
 
 /* ---- measurement ------------------------------------------------------- */
 int bce_timing_reset(bce_ctx*);

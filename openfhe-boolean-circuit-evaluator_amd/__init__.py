@@ -56,7 +56,7 @@ ENGINE_SYMBOLS = [
     "bce_ctx_create", "bce_ctx_create_custom", "bce_ctx_destroy", "bce_last_error", "bce_get_params",
     "bce_keygen", "bce_import_keys", "bce_import_keys_file", "bce_export_keys_file", "bce_bsk_words", "bce_ksk_words", "bce_export_sk", "bce_export_bsk",
     "bce_export_ksk", "bce_pool_reserve", "bce_pool_slots", "bce_lwe_write", "bce_lwe_read",
-    "bce_encrypt_bits", "bce_set_encrypt_seed", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize", "bce_set_lanes",
+    "bce_encrypt_bits", "bce_set_encrypt_seed", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize",
     "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_rccl_available", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
     "bce_rccl_shutdown", "bce_debug_eval_stages", "bce_debug_ntt",
 ]
@@ -108,7 +108,6 @@ def lib():
     L.bce_eval_gates.argtypes = [vp, u32, vp]
     L.bce_eval_gates_strided.argtypes = [vp, u32, vp, u32, u32]
     L.bce_synchronize.argtypes = [vp]
-    L.bce_set_lanes.argtypes = [vp, u32]
     L.bce_timing_reset.argtypes = [vp]
     L.bce_timing_get.argtypes = [vp, C.POINTER(Timing)]
     L.bce_bytes_per_bootstrap.argtypes = [vp]
@@ -262,10 +261,6 @@ class BinFHEContext:
 
     def EvalNOT(self, in0, out):
         self.EvalGates([(OP_NOT, in0, in0, out)])
-
-    def set_lanes(self, lanes):
-        """split strided calls over `lanes` streams (independent instance groups overlap their launches)"""
-        self._ck(self._L.bce_set_lanes(self.h, int(lanes)))
 
     def synchronize(self):
         self._ck(self._L.bce_synchronize(self.h))

@@ -105,30 +105,11 @@ struct bce_ctx {
     size_t acc_cap = 0;  // bootstraps
     u64* d_tail_partial = nullptr;  // partial key-switch sums (kernels.hip, k_tail_gather)
     size_t tail_cap = 0;            // u64 words
-    // Lanes (bce_set_lanes): the K lock-step instances of a strided call are split into contiguous groups, each
-    // evaluated on a HIP stream of its own with its own work buffers.  Instances never depend on each other, so the
-    // lanes drift apart and their launches overlap: a frontier too narrow to fill the chip no longer leaves it
-    // half-empty between two dependent launches.  The main stream keeps the descriptor uploads (so that no lane's
-    // next level queues behind another lane's kernel) and every call that is not split.
-    struct Lane {
-        hipStream_t stream = nullptr;
-        void* d_acc = nullptr;
-        size_t acc_cap = 0;
-        u64* d_tail_partial = nullptr;
-        size_t tail_cap = 0;
-        hipEvent_t last = nullptr;    // recorded after the lane's latest work
-        bool busy = false;            // has work the main stream has not been ordered after
-    };
-    std::vector<Lane> lanes;          // empty: everything on the main stream
-    static constexpr int kMaxLanes = 4;
     static constexpr int kRing = 4;
     bce_gate_desc* d_descs[kRing] = {nullptr, nullptr, nullptr, nullptr};
     bce_gate_desc* h_descs[kRing] = {nullptr, nullptr, nullptr, nullptr};
     size_t desc_cap[kRing] = {0, 0, 0, 0};
-    hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};   // main stream: after the last reader of the slot
-    hipEvent_t ring_up[kRing] = {nullptr, nullptr, nullptr, nullptr};   // main stream: descriptor upload done
-    hipEvent_t ring_lane_ev[kRing][4] = {};                              // per lane: after its readers of the slot
-    bool ring_lane_busy[kRing][4] = {};
+    hipEvent_t ring_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
     bool ring_busy[kRing] = {false, false, false, false};
     int ring_pos = 0;
     // timing
@@ -214,11 +195,7 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     hipMemcpy(c->d_twf, twf.data(), sizeof(uint2) * N, hipMemcpyHostToDevice);
     if (hipMalloc(&c->d_psi, sizeof(u32) * N) != hipSuccess) { g_create_error = "hipMalloc(psi table) failed"; return BCE_ERR_HIP; }
     hipMemcpy(c->d_psi, psitab.data(), sizeof(u32) * N, hipMemcpyHostToDevice);
-    for (int i = 0; i < bce_ctx::kRing; ++i) {
-        hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming);
-        hipEventCreateWithFlags(&c->ring_up[i], hipEventDisableTiming);
-    }
-
+    for (int i = 0; i < bce_ctx::kRing; ++i) hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming);
 
     DevParams& P = c->P;
     P.n = n; P.N = N; P.logN = c->logN; P.q = (u32)q; P.Q = (u32)Q; P.qKS = (u32)c->qKS;
@@ -366,52 +343,14 @@ int upload_ksk(bce_ctx* c, const u32* ksk) {
     return BCE_OK;
 }
 
-// wait (on the host) for the main stream and every lane
-int sync_all(bce_ctx* c) {
+int ensure_acc(bce_ctx* c, size_t boots) {
+    if (boots <= c->acc_cap) return BCE_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (auto& ln : c->lanes) {
-        HIP_TRY(c, hipStreamSynchronize(ln.stream));
-        ln.busy = false;
-    }
-    return BCE_OK;
-}
-// order the main stream after everything the lanes have been given (device-side wait, the host does not block)
-int join_lanes(bce_ctx* c) {
-    for (auto& ln : c->lanes)
-        if (ln.busy) {
-            HIP_TRY(c, hipStreamWaitEvent(c->stream, ln.last, 0));
-            ln.busy = false;
-        }
-    return BCE_OK;
-}
-// accumulator hand-off / partial-sum buffers of one lane (lane < 0: the main stream's own)
-int ensure_lane_buffers(bce_ctx* c, int lane, size_t boots, bool need_tail, void** acc, u64** partial) {
-    void*& d_acc = lane >= 0 ? c->lanes[lane].d_acc : c->d_acc;
-    size_t& acc_cap = lane >= 0 ? c->lanes[lane].acc_cap : c->acc_cap;
-    u64*& d_part = lane >= 0 ? c->lanes[lane].d_tail_partial : c->d_tail_partial;
-    size_t& part_cap = lane >= 0 ? c->lanes[lane].tail_cap : c->tail_cap;
-    hipStream_t s = lane >= 0 ? c->lanes[lane].stream : c->stream;
-    if (boots > acc_cap) {
-        HIP_TRY(c, hipStreamSynchronize(s));
-        if (d_acc) hipFree(d_acc);
-        d_acc = nullptr;
-        const size_t cap = std::max(boots, acc_cap * 2);
-        HIP_TRY(c, hipMalloc(&d_acc, cap * 2 * c->N * c->wbytes));
-        acc_cap = cap;
-    }
-    if (need_tail) {
-        const size_t need = tail_partial_words(c->P, (u32)boots);
-        if (need > part_cap) {
-            HIP_TRY(c, hipStreamSynchronize(s));
-            if (d_part) hipFree(d_part);
-            d_part = nullptr;
-            const size_t cap = std::max(need, part_cap * 2);
-            HIP_TRY(c, hipMalloc(&d_part, cap * sizeof(u64)));
-            part_cap = cap;
-        }
-    }
-    *acc = d_acc;
-    *partial = d_part;
+    if (c->d_acc) hipFree(c->d_acc);
+    c->d_acc = nullptr;
+    size_t cap = std::max(boots, c->acc_cap * 2);
+    HIP_TRY(c, hipMalloc(&c->d_acc, cap * 2 * c->N * c->wbytes));
+    c->acc_cap = cap;
     return BCE_OK;
 }
 
@@ -423,11 +362,6 @@ int stage_descs(bce_ctx* c, const bce_gate_desc* d, size_t n, bce_gate_desc** de
         HIP_TRY(c, hipEventSynchronize(c->ring_ev[k]));
         c->ring_busy[k] = false;
     }
-    for (int l = 0; l < bce_ctx::kMaxLanes; ++l)
-        if (c->ring_lane_busy[k][l]) {
-            HIP_TRY(c, hipEventSynchronize(c->ring_lane_ev[k][l]));
-            c->ring_lane_busy[k][l] = false;
-        }
     if (n > c->desc_cap[k]) {
         if (c->d_descs[k]) hipFree(c->d_descs[k]);
         if (c->h_descs[k]) hipHostFree(c->h_descs[k]);
@@ -438,7 +372,6 @@ int stage_descs(bce_ctx* c, const bce_gate_desc* d, size_t n, bce_gate_desc** de
     }
     std::memcpy(c->h_descs[k], d, n * sizeof(bce_gate_desc));
     HIP_TRY(c, hipMemcpyAsync(c->d_descs[k], c->h_descs[k], n * sizeof(bce_gate_desc), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ring_up[k], c->stream));
     *dev = c->d_descs[k];
     *slot = k;
     return BCE_OK;
@@ -567,80 +500,53 @@ int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances,
         if (hi + max_slot >= c->pool_slots) return c->fail(BCE_ERR_POOL, "descriptor %u: slot %llu outside the pool (%u slots)", i, (unsigned long long)(hi + max_slot), c->pool_slots);
         (is_boot ? boot : unary).push_back(g);
     }
-    // Lanes: a strided call over enough instances is split into contiguous instance groups, one per lane (stream).
-    // Anything else runs on the main stream, ordered after whatever the lanes still have in flight.
-    const bool dbg = dbg_acc || dbg_lweN || dbg_ks;
-    const bool split = !dbg && c->lanes.size() > 1 && instances >= c->lanes.size();
-    const size_t L = split ? c->lanes.size() : 1;
-    if (!split) {
-        int rc = join_lanes(c);
-        if (rc) return rc;
-    }
-    auto lane_range = [&](size_t l, u32* i0, u32* cnt) {
-        *i0 = (u32)((u64)instances * l / L);
-        *cnt = (u32)((u64)instances * (l + 1) / L) - *i0;
-    };
-    // after a lane's launches that read descriptor slot `slot`
-    auto lane_done = [&](size_t l, int slot) -> int {
-        if (!split) {
-            HIP_TRY(c, hipEventRecord(c->ring_ev[slot], c->stream));
-            c->ring_busy[slot] = true;
-        } else {
-            if (!c->ring_lane_ev[slot][l]) HIP_TRY(c, hipEventCreateWithFlags(&c->ring_lane_ev[slot][l], hipEventDisableTiming));
-            HIP_TRY(c, hipEventRecord(c->ring_lane_ev[slot][l], c->lanes[l].stream));
-            c->ring_lane_busy[slot][l] = true;
-            HIP_TRY(c, hipEventRecord(c->lanes[l].last, c->lanes[l].stream));
-            c->lanes[l].busy = true;
-        }
-        return BCE_OK;
-    };
     if (!boot.empty()) {
         const size_t nb = boot.size() * (size_t)instances;
+        int rc = ensure_acc(c, nb);
+        if (rc) return rc;
         bce_gate_desc* dd = nullptr;
         int slot = 0;
-        int rc = stage_descs(c, boot.data(), boot.size(), &dd, &slot);
+        rc = stage_descs(c, boot.data(), boot.size(), &dd, &slot);
         if (rc) return rc;
         u32 *d_lweN = nullptr, *d_ks = nullptr;
         if (dbg_lweN) HIP_TRY(c, hipMalloc(&d_lweN, nb * (c->N + 1) * sizeof(u32)));
         if (dbg_ks) HIP_TRY(c, hipMalloc(&d_ks, nb * (c->n + 1) * sizeof(u32)));
-        for (size_t l = 0; l < L; ++l) {
-            u32 i0, cnt;
-            lane_range(l, &i0, &cnt);
-            if (cnt == 0) continue;
-            hipStream_t st = split ? c->lanes[l].stream : c->stream;
-            if (split) HIP_TRY(c, hipStreamWaitEvent(st, c->ring_up[slot], 0));   // descriptors uploaded (and all earlier main-stream work)
-            const size_t nbl = boot.size() * (size_t)cnt;
-            // the separate tail is only needed when the blind-rotation kernel does not fuse it; size its buffer anyway (cheap)
-            void* acc = nullptr;
-            u64* partial = nullptr;
-            if ((rc = ensure_lane_buffers(c, split ? (int)l : -1, nbl, true, &acc, &partial))) return rc;
-            DevParams Pl = c->P;
-            Pl.pool = c->P.pool + (size_t)i0 * slot_stride * c->P.pool_stride;   // the lane's instances start here
-            EventPair e0 = get_events(c, 0);
-            int kid = BCE_BR_WORD64;
-            bool tail_fused = false;
-            hipEventRecord(e0.a, st);
-            if (c->is64) HIP_TRY(c, launch_blind_rotate64(Pl, dd, (u32)boot.size(), cnt, slot_stride, static_cast<u64*>(acc), st));
-            else HIP_TRY(c, launch_blind_rotate(Pl, dd, (u32)boot.size(), cnt, slot_stride, static_cast<u32*>(acc), st, &kid, d_lweN, d_ks, &tail_fused));
-            hipEventRecord(e0.b, st);
-            e0.kind = kid;
-            c->pending.push_back(e0);
-            c->timing.br_launches[kid] += 1;
-            c->timing.br_bootstraps[kid] += nbl;
-            if (!tail_fused) {
-                EventPair e1 = get_events(c, BCE_BR_KERNELS);  // kind >= BCE_BR_KERNELS: tail
-                hipEventRecord(e1.a, st);
-                HIP_TRY(c, launch_tail(Pl, dd, (u32)boot.size(), cnt, slot_stride, acc, partial, d_lweN, d_ks, st));
-                hipEventRecord(e1.b, st);
-                c->pending.push_back(e1);
-            } else {
-                c->timing.fused_tail_launches += 1;
+        EventPair e0 = get_events(c, 0);
+        int kid = BCE_BR_WORD64;
+        bool tail_fused = false;
+        hipEventRecord(e0.a, c->stream);
+        if (c->is64) HIP_TRY(c, launch_blind_rotate64(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u64*>(c->d_acc), c->stream));
+        else HIP_TRY(c, launch_blind_rotate(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u32*>(c->d_acc), c->stream, &kid, d_lweN, d_ks, &tail_fused));
+        hipEventRecord(e0.b, c->stream);
+        e0.kind = kid;
+        c->pending.push_back(e0);
+        c->timing.br_launches[kid] += 1;
+        c->timing.br_bootstraps[kid] += nb;
+        if (!tail_fused) {
+            EventPair e1 = get_events(c, BCE_BR_KERNELS);  // kind >= BCE_BR_KERNELS: tail
+            hipEventRecord(e1.a, c->stream);
+            {
+                const size_t need = tail_partial_words(c->P, (u32)nb);
+                if (need > c->tail_cap) {
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    if (c->d_tail_partial) hipFree(c->d_tail_partial);
+                    c->d_tail_partial = nullptr;
+                    const size_t cap = std::max(need, c->tail_cap * 2);
+                    HIP_TRY(c, hipMalloc(&c->d_tail_partial, cap * sizeof(u64)));
+                    c->tail_cap = cap;
+                }
             }
-            if ((rc = lane_done(l, slot))) return rc;
-            c->timing.blind_rotate_launches += 1;
+            HIP_TRY(c, launch_tail(c->P, dd, (u32)boot.size(), instances, slot_stride, c->d_acc, c->d_tail_partial, d_lweN, d_ks, c->stream));
+            hipEventRecord(e1.b, c->stream);
+            c->pending.push_back(e1);
+        } else {
+            c->timing.fused_tail_launches += 1;
         }
+        hipEventRecord(c->ring_ev[slot], c->stream);
+        c->ring_busy[slot] = true;
+        c->timing.blind_rotate_launches += 1;
         c->timing.bootstraps += nb;
-        if (dbg) {
+        if (dbg_acc || dbg_lweN || dbg_ks) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             std::vector<u32> tmp;
             auto fetch = [&](const u32* dev, size_t words, u64* dst) -> int {
@@ -657,7 +563,7 @@ int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances,
             if (d_ks) hipFree(d_ks);
         }
         if (c->pending.size() > 4096) {
-            if ((rc = sync_all(c))) return rc;
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
             drain_timing(c);
         }
     }
@@ -666,17 +572,9 @@ int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances,
         int slot = 0;
         int rc = stage_descs(c, unary.data(), unary.size(), &dd, &slot);
         if (rc) return rc;
-        for (size_t l = 0; l < L; ++l) {
-            u32 i0, cnt;
-            lane_range(l, &i0, &cnt);
-            if (cnt == 0) continue;
-            hipStream_t st = split ? c->lanes[l].stream : c->stream;
-            if (split) HIP_TRY(c, hipStreamWaitEvent(st, c->ring_up[slot], 0));
-            DevParams Pl = c->P;
-            Pl.pool = c->P.pool + (size_t)i0 * slot_stride * c->P.pool_stride;
-            HIP_TRY(c, launch_lwe_unary(Pl, dd, (u32)unary.size(), cnt, slot_stride, st));
-            if ((rc = lane_done(l, slot))) return rc;
-        }
+        HIP_TRY(c, launch_lwe_unary(c->P, dd, (u32)unary.size(), instances, slot_stride, c->stream));
+        hipEventRecord(c->ring_ev[slot], c->stream);
+        c->ring_busy[slot] = true;
     }
     return BCE_OK;
 }
@@ -701,13 +599,6 @@ void bce_ctx_destroy(bce_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    for (auto& ln : c->lanes) {
-        if (ln.stream) { hipStreamSynchronize(ln.stream); hipStreamDestroy(ln.stream); }
-        if (ln.last) hipEventDestroy(ln.last);
-        hipFree(ln.d_acc);
-        hipFree(ln.d_tail_partial);
-    }
-    c->lanes.clear();
     if (c->rccl_comm) bce_rccl_shutdown(c);
     drain_timing(c);
     for (auto& p : c->free_events) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -715,8 +606,6 @@ void bce_ctx_destroy(bce_ctx* c) {
         if (c->d_descs[i]) hipFree(c->d_descs[i]);
         if (c->h_descs[i]) hipHostFree(c->h_descs[i]);
         if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
-        if (c->ring_up[i]) hipEventDestroy(c->ring_up[i]);
-        for (int l = 0; l < bce_ctx::kMaxLanes; ++l) if (c->ring_lane_ev[i][l]) hipEventDestroy(c->ring_lane_ev[i][l]);
     }
     hipFree(c->d_twf); hipFree(c->d_psi); hipFree(c->d_tw64); hipFree(c->d_tw64d); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc); hipFree(c->d_tail_partial);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -754,9 +643,8 @@ int bce_keygen(bce_ctx* c, const uint8_t seed_in[32]) {
         seed = fresh;
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = sync_all(c);
+    int rc = alloc_keys(c);
     if (rc) return rc;
-    if ((rc = alloc_keys(c))) return rc;
     std::memcpy(c->seed, seed, 32);
     const u32 n = c->n, N = c->N;
     const GaussSampler gauss(3.19);
@@ -875,7 +763,7 @@ int bce_pool_reserve(bce_ctx* c, uint32_t slots) {
     if (!c) return BCE_ERR_ARG;
     if (slots <= c->pool_slots) return BCE_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    { const int rc_ = sync_all(c); if (rc_) return rc_; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     u32* np = nullptr;
     HIP_TRY(c, hipMalloc(&np, (size_t)slots * c->P.pool_stride * 4));
     HIP_TRY(c, hipMemset(np, 0, (size_t)slots * c->P.pool_stride * 4));
@@ -895,7 +783,7 @@ int bce_lwe_write(bce_ctx* c, const uint32_t* slots, uint32_t count, const uint6
     if (!c || !slots || !cts) return BCE_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t W = c->n + 1;
-    { const int rc_ = sync_all(c); if (rc_) return rc_; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     std::vector<u32> buf;
     for (u32 i = 0; i < count;) {
         u32 run = 1;  // coalesce runs of consecutive slots into one copy
@@ -917,7 +805,7 @@ int bce_lwe_read(bce_ctx* c, const uint32_t* slots, uint32_t count, uint64_t* ct
     if (!c || !slots || !cts) return BCE_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t W = c->n + 1;
-    { const int rc_ = sync_all(c); if (rc_) return rc_; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     // one bulk copy when the request is dense enough, else per slot
     u32 lo = ~0u, hi = 0;
     for (u32 i = 0; i < count; ++i) {
@@ -1024,40 +912,16 @@ int bce_eval_gates_strided(bce_ctx* c, uint32_t n_desc, const bce_gate_desc* des
     return eval_impl(c, n_desc, descs, instances, slot_stride, nullptr, nullptr, nullptr);
 }
 
-int bce_set_lanes(bce_ctx* c, uint32_t lanes) {
-    if (!c) return BCE_ERR_ARG;
-    if (lanes == 0 || lanes > (uint32_t)bce_ctx::kMaxLanes) return c->fail(BCE_ERR_ARG, "lanes must be 1..%d", bce_ctx::kMaxLanes);
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = sync_all(c);
-    if (rc) return rc;
-    const size_t want = lanes > 1 ? lanes : 0;   // one lane = everything on the main stream
-    while (c->lanes.size() > want) {
-        auto& ln = c->lanes.back();
-        if (ln.stream) hipStreamDestroy(ln.stream);
-        if (ln.last) hipEventDestroy(ln.last);
-        hipFree(ln.d_acc);
-        hipFree(ln.d_tail_partial);
-        c->lanes.pop_back();
-    }
-    while (c->lanes.size() < want) {
-        bce_ctx::Lane ln;
-        HIP_TRY(c, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&ln.last, hipEventDisableTiming));
-        c->lanes.push_back(ln);
-    }
-    return BCE_OK;
-}
-
 int bce_synchronize(bce_ctx* c) {
     if (!c) return BCE_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    { const int rc_ = sync_all(c); if (rc_) return rc_; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return BCE_OK;
 }
 
 int bce_timing_reset(bce_ctx* c) {
     if (!c) return BCE_ERR_ARG;
-    { const int rc_ = sync_all(c); if (rc_) return rc_; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_timing(c);
     c->timing = bce_timing{};
     return BCE_OK;
@@ -1065,7 +929,7 @@ int bce_timing_reset(bce_ctx* c) {
 
 int bce_timing_get(bce_ctx* c, bce_timing* out) {
     if (!c || !out) return BCE_ERR_ARG;
-    { const int rc_ = sync_all(c); if (rc_) return rc_; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_timing(c);
     *out = c->timing;
     return BCE_OK;
@@ -1111,9 +975,8 @@ static int pool_pack(bce_ctx* c, const uint32_t* slots, uint32_t count, void* de
     }
     bce_gate_desc* dd = nullptr;
     int slot = 0;
-    int rc = join_lanes(c);
+    int rc = stage_descs(c, d.data(), count, &dd, &slot);
     if (rc) return rc;
-    if ((rc = stage_descs(c, d.data(), count, &dd, &slot))) return rc;
     HIP_TRY(c, launch_pool_pack(c->P, dd, count, (u32*)dev, to_pool, c->stream));
     hipEventRecord(c->ring_ev[slot], c->stream);
     c->ring_busy[slot] = true;

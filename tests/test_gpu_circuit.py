@@ -369,40 +369,3 @@ def test_bristol_fashion_constants_mand_buses_encrypted(bce, orc, toy_cc, tmp_pa
     q = o.params["q"]
     assert not regs[5][:-1].any() and regs[5][-1] == q // 4 and not regs[6].any()
     assert np.array_equal(regs[9], o.eval_bingate(orc.AND, regs[7], regs[5]))
-
-
-@pytest.mark.parametrize("lanes", [2, 3])
-def test_lanes_same_ciphertexts_as_one_stream(bce, std_cc, lanes):
-    """bce_set_lanes: the K lock-step instances split over several HIP streams (their launches overlap) must leave exactly
-    the registers a single stream leaves -- adder_64bit, K = 7 (uneven split), gate-level schedule with its NOT / COPY
-    launches, then a per-gate (unsplit) evaluation on the main stream right behind the split one."""
-    c = bce.Circuit(std_cc)
-    c.ReadBristol(os.path.join(CIRCUITS, "adder_64bit.txt"))
-    K = 7
-    c.setInstances(K)
-    cases = [kat.adder_case(t, 64) for t in range(K)]
-    c.Reset()
-    c.setEncrypted(True)
-    for k, (ins, _) in enumerate(cases):
-        c.SetInput(ins, instance=k)
-    stride, nw = c.info()["slot_stride"], c.info()["n_wires"]
-    regs = np.concatenate([np.arange(nw, dtype=np.uint32) + k * stride for k in range(K)])
-    try:
-        std_cc.set_lanes(1)
-        c.Clock()
-        want = std_cc.lwe_read(regs)
-        outs = [c.Outputs(k)[0] for k in range(K)]
-        assert outs == [w for _, w in cases]
-        std_cc.set_lanes(lanes)
-        c.Rearm()
-        c.Clock()
-        assert [c.Outputs(k)[0] for k in range(K)] == outs
-        assert np.array_equal(std_cc.lwe_read(regs), want), "registers differ between %d lanes and one stream" % lanes
-        # a call that cannot be split (one instance) right after split ones: ordered behind the lanes
-        c.setRelevel(True)
-        c.Rearm()
-        c.Clock()
-        std_cc.EvalGates([(bce.OP_COPY, int(regs[5]), 0, int(regs[5]))])
-        assert np.array_equal(std_cc.lwe_read(regs), want)
-    finally:
-        std_cc.set_lanes(1)

@@ -28,8 +28,7 @@ CONFIGS = [
 
 
 def main():
-    only = [a for a in sys.argv[1:] if not a.startswith("--")]
-    lanes_list = [1, 2] if "--lanes" in sys.argv else [1]
+    only = sys.argv[1:]
     ctxs = {}
     rows = []
     for name, fname, kind, ps, method, Ks in CONFIGS:
@@ -41,8 +40,7 @@ def main():
             cc.KeyGen(0x0FE5EED)
             ctxs[key] = cc
         cc = ctxs[key]
-        for K, lanes in [(K, l) for K in Ks for l in lanes_list if l == 1 or K >= 8]:
-            cc.set_lanes(lanes)
+        for K in Ks:
             c = bce.Circuit(cc)
             path = os.path.join(kat.CIRCUITS, fname)
             if kind == "out":
@@ -70,13 +68,12 @@ def main():
             dt = time.time() - t0
             ok = all(c.Outputs(k)[0] == want[k] for k in range(K))
             st = c.stats()
-            row = {"config": name, "K": K, "lanes": lanes, "bootstraps_per_eval": info["n_bootstraps"], "sublaunches": info["n_sublaunches"],
+            row = {"config": name, "K": K, "bootstraps_per_eval": info["n_bootstraps"], "sublaunches": info["n_sublaunches"],
                    "seconds": round(dt, 3), "bootstraps_per_s": round(st["bootstraps"] / dt), "ms_per_sublaunch": round(dt / max(1, st["sublaunches"]) * 1e3, 3),
                    "correct": ok}
             rows.append(row)
             print(json.dumps(row), flush=True)
             c.close()
-            cc.set_lanes(1)
     return rows
 
 
