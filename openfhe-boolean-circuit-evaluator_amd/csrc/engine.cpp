@@ -614,6 +614,7 @@ void bce_ctx_destroy(bce_ctx* c) {
 
 hipStream_t bce_internal_stream(bce_ctx* c) { return c->stream; }
 void** bce_internal_comm_slot(bce_ctx* c) { return &c->rccl_comm; }
+int bce_internal_device(bce_ctx* c) { return c->device; }
 int bce_rccl_shutdown(bce_ctx* c);
 
 int bce_set_error(bce_ctx* c, int code, const char* msg) {  // for the other translation units of the library (keyfile.cpp)

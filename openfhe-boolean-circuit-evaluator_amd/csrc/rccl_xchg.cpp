@@ -21,6 +21,7 @@
 extern "C" int bce_set_error(bce_ctx* c, int code, const char* msg);                  // engine.cpp
 extern "C" hipStream_t bce_internal_stream(bce_ctx* c);                                // engine.cpp
 extern "C" void** bce_internal_comm_slot(bce_ctx* c);                                  // engine.cpp: where the communicator lives
+extern "C" int bce_internal_device(bce_ctx* c);                                        // engine.cpp: the context's HIP device
 
 namespace {
 
@@ -94,7 +95,8 @@ int bce_rccl_init(bce_ctx* c, const uint8_t uid[128], int rank, int world) {
     if (*slot) { r.comm_destroy(*slot); *slot = nullptr; }
     UniqueId id;
     std::memcpy(id.internal, uid, 128);
-    const int rc = r.comm_init_rank(slot, world, id, rank);   // binds to the device current on this thread (the engine's)
+    if (hipSetDevice(bce_internal_device(c)) != hipSuccess) return bce_set_error(c, BCE_ERR_HIP, "hipSetDevice failed");
+    const int rc = r.comm_init_rank(slot, world, id, rank);   // binds to the device current on this thread: the engine's
     if (rc != 0) { *slot = nullptr; return fail_nccl(c, "ncclCommInitRank", rc); }
     return BCE_OK;
 }
