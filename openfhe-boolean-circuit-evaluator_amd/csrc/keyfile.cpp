@@ -20,6 +20,8 @@
 
 extern "C" int bce_set_error(bce_ctx* c, int code, const char* msg);  // engine.cpp
 
+static_assert(sizeof(bce_keyfile_header) == 104, "on-disk header layout (tools/openfhe_export/bce_keyfile.h)");
+
 namespace {
 struct Mapping {
     int fd = -1;
