@@ -266,6 +266,25 @@ def main():
     shard_mode = 0 if args.shard == "instances" else 1
     R = run_mode(shard_mode, args.steps, args.warmup, args.relevel)
     setup_s = R["t_ready"] - t_setup     # context + keygen + parsing + plaintext pass + input encryption
+    # also the end-to-end latency of ONE input block (K = 1: every dependent launch is a single narrow frontier)
+    def single_block_latency():
+        c1 = bce.Circuit(cc)
+        c1.ReadBristol(path, new_flag=args.circuit.startswith("sha256_new"))
+        if args.relevel:
+            c1.setRelevel(True)
+        c1.Reset()
+        c1.setEncrypted(True)
+        w = [x for x in c1.info()["n_input_bits"] if x]
+        c1.SetInput([np.random.default_rng(5).integers(0, 2, x).tolist() for x in w])
+        c1.Clock()
+        c1.Rearm()
+        cc.synchronize()
+        t0 = time.time()
+        c1.Clock()
+        dt = time.time() - t0
+        c1.close()
+        return dt
+    block_latency_s = single_block_latency()
     G = G_err = None
     if world > 1 and shard_mode == 0 and args.gates_steps > 0:
         try:        # a failure of the secondary run (on every rank alike) must not cost the headline line
@@ -368,6 +387,8 @@ def main():
                 "schedule": "bootstrap-depth levels (NOTs folded, identical ciphertexts)" if R["relevel"] else "gate levels (reference Clock rounds)",
                 "xor": "XOR_FAST (opt-in, 1 bootstrap)" if args.xor_fast else "NOT,NOT,AND,AND,OR (reference, 3 bootstraps)",
                 "bootstraps_per_step": int(total_boot / args.steps),
+                "gates_per_s": (info["n_gates"] - info["n_output_bits"]) * args.instances * world * args.steps / elapsed,
+                "single_block_latency_s": round(block_latency_s, 4),
                 "outputs_verified": bool(verified), "setup_s": round(setup_s, 2), "keygen_s": round(keygen_s, 3),
                 "host_share_of_step": round(1.0 - (tm["blind_rotate_ms"] + tm["tail_ms"]) / (elapsed * 1e3), 4),
                 "exchanges_per_step": R["exchanges_per_step"], "exchanged_cts_per_step": R["exchanged_cts_per_step"],
