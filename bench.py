@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--xor-fast", action="store_true", help="opt-in native XOR (NOT the reference's XOR = 3 bootstraps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--gates-timeout", type=int, default=150, help="N > 1: watchdog (s) over the secondary run and the teardown")
     ap.add_argument("--gates-steps", type=int, default=2, help="N > 1: timed steps of the secondary gate-sharded run (0 = skip)")
     args = ap.parse_args()
 
@@ -286,11 +287,7 @@ def main():
         return dt
     block_latency_s = single_block_latency()
     G = G_err = None
-    if world > 1 and shard_mode == 0 and args.gates_steps > 0:
-        try:        # a failure of the secondary run (on every rank alike) must not cost the headline line
-            G = run_mode(1, args.gates_steps, 1, False)
-        except Exception as e:
-            G_err = repr(e)
+    out = None
     elapsed, total_boot, verified, tm, info = R["elapsed"], R["total_boot"], R["verified"], R["tm"], R["info"]
 
     def load_profile(name):
@@ -397,6 +394,44 @@ def main():
             },
             "roofline": roof,
         }
+
+    # ---- the headline object exists from here on; everything below (secondary gate-sharded run on N > 1, teardown of the
+    # process group) runs under a watchdog, so that a collective that never returns costs the secondary object, not the line
+    import threading
+    emit_lock = threading.Lock()
+    state = {"printed": False}
+
+    def emit():
+        if rank == 0 and not state["printed"]:
+            state["printed"] = True
+            if not out.get("config", {}).get("outputs_verified", False):
+                out["error"] = "decrypted outputs differ from the plaintext evaluation"
+            print(json.dumps(out), flush=True)
+
+    def on_timeout():
+        with emit_lock:
+            if rank == 0 and not state["printed"]:
+                out["shard_gates"] = {"error": "gate-sharded secondary run / teardown did not finish within %d s: abandoned" % args.gates_timeout}
+                emit()
+            sys.stderr.write("bench.py: rank %d watchdog fired after %d s\n" % (rank, args.gates_timeout))
+            sys.stderr.flush()
+            os._exit(0 if verified else 2)
+
+    wd = None
+    if world > 1:
+        wd = threading.Timer(args.gates_timeout, on_timeout)
+        wd.daemon = True
+        wd.start()
+    if world > 1 and shard_mode == 0 and args.gates_steps > 0:
+        try:        # a failure of the secondary run must not cost the headline line
+            if os.environ.get("BCE_BENCH_TEST_HANG") == "1" and rank == world - 1:
+                time.sleep(1e6)      # test hook (tests/test_bench_launch.py): one rank never reaches the collective
+            G = run_mode(1, args.gates_steps, 1, False)
+        except Exception as e:
+            G_err = repr(e)
+    if G is not None:
+        verified = verified and G["verified"]
+    if rank == 0:
         if G_err is not None:
             out["shard_gates"] = {"error": G_err}
         if G is not None:
@@ -409,17 +444,17 @@ def main():
                 "exchange_path": G["exchange_path"],
                 "outputs_verified": bool(G["verified"]),
             }
-            verified = verified and G["verified"]
+            if not G["verified"]:
+                out["error"] = "gate-sharded run: decrypted outputs differ from the plaintext evaluation"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        if not verified:
-            out["error"] = "decrypted outputs differ from the plaintext evaluation"
-        print(json.dumps(out), flush=True)
-    elif G is not None:
-        verified = verified and G["verified"]
+        with emit_lock:
+            emit()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if wd is not None:
+        wd.cancel()
     if not verified:
         sys.exit(2)
 

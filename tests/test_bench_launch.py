@@ -13,8 +13,8 @@ import pytest
 from conftest import ROOT
 
 
-def _run(args, timeout):
-    env = dict(os.environ, BCE_BENCH_SINGLE_DEVICE="1", BCE_BENCH_BACKEND="gloo")
+def _run(args, timeout, **extra):
+    env = dict(os.environ, BCE_BENCH_SINGLE_DEVICE="1", BCE_BENCH_BACKEND="gloo", **extra)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
@@ -53,3 +53,18 @@ def test_bench_gpus2_rehearsal_on_one_gpu():
     assert g["outputs_verified"] is True and g["scaling"] == "strong"
     assert g["exchanges_per_step"] > 0 and g["exchanged_cts_per_step"] > 0
     assert "roofline" in d and "cpu_baseline" not in d               # the CPU baseline is an N = 1 leg
+
+
+@pytest.mark.gpu
+def test_bench_headline_survives_a_hung_secondary_run():
+    """A rank that never reaches the gate-sharded run's collectives (simulated) must cost the `shard_gates` object
+    only: the watchdog prints the one JSON line with the headline and ends every rank."""
+    p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--circuit", "adder_32bit.txt", "--instances", "4",
+              "--gates-steps", "1", "--gates-timeout", "25"], timeout=600, BCE_BENCH_TEST_HANG="1")
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, p.stdout
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["config"]["outputs_verified"] is True and d["value"] > 0
+    assert "did not finish" in d["shard_gates"]["error"]
+    assert "watchdog fired" in p.stderr
