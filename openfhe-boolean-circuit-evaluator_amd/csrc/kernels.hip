@@ -135,6 +135,16 @@ __device__ __forceinline__ void block_sync_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// exchange that stays inside one wave (split inverse transform, passes 0..3).  -DBCE_STEP_BARRIERS restores the
+// workgroup barriers of the round-1 schedule for A/B runs (tools/barrier_ab.sh).
+__device__ __forceinline__ void wave_sync();
+__device__ __forceinline__ void wave_local_sync() {
+#ifdef BCE_STEP_BARRIERS
+    block_sync_lds();
+#else
+    wave_sync();
+#endif
+}
 __device__ __forceinline__ void wave_sync() {
     // LDS operations of one wave execute in order; this only pins the compiler.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -803,8 +813,12 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
 // the key-row load latency twice per step.  This variant is for launches that leave CUs to themselves:
 //   * each inverse transform is split over FOUR waves: 256 threads x 4 coefficients, five 2-stage passes
 //     exchanged through two ping-pong LDS buffers whose layouts are bank-conflict free on both sides
-//     with compile-time register offsets (e0: padded natural, e1: p[3:0] + 20 p[5:4] + 80 p[7:6] + 320 p[9:8],
-//     e2: p[5:0] + 80 p[7:6] + 320 p[9:8], e3: natural);
+//     with compile-time register offsets (e0: 320 p[9:8] + padded natural, e1: p[3:0] + 20 p[5:4] + 80 p[7:6] +
+//     320 p[9:8], e2: p[5:0] + 80 p[7:6] + 320 p[9:8], e3: 320 p[9:8] + p[7:0]).  Every layout keeps the 256
+//     positions of one wave (p[9:8] = wave of the group through passes 0..3) in that wave's own 320 words, and the
+//     exchanges after passes 0, 1, 2 only swap register bits with LANE bits: they stay inside the wave and need no
+//     workgroup barrier.  Only the exchange before the last pass (position bits 9:8 <-> wave) crosses waves: one
+//     barrier per inverse transform, three per step (before pass 4, around the forward transforms);
 //   * the thread <-> data mappings line up across phases, so two passes are fused away: the MAC thread owns
 //     the 4 consecutive positions of inverse pass 0 and runs it on the words it has just accumulated; after the
 //     inverse transform a thread holds coefficients t + 256 r, i.e. bits 9 and 8 in registers, and applies the
@@ -849,7 +863,7 @@ __device__ __forceinline__ void inv_pass4_last(u32 (&x)[4], uint2 fa, uint2 fb, 
 // in registers for the whole bootstrap; otherwise only their table positions do and they are re-read per step.
 template <bool REGTW>
 struct SplitInv {
-    u32 a0, l1, s1, l2, s2, l3, s3, t;
+    u32 a0, x0, l1, s1, l2, s2, l3, s3, t;   // a0: the thread's 4 words in an accumulator row, x0: in exchange layout e0
     uint2 fa[REGTW ? 5 : 1], fb[REGTW ? 5 : 1], fc[REGTW ? 4 : 1];
     u32 ia[REGTW ? 1 : 4], ic[REGTW ? 1 : 4];  // positions of fa (fb sits at the entry with index - 1) and fc
 };
@@ -857,10 +871,12 @@ template <bool REGTW>
 __device__ __forceinline__ void split_inv_setup(SplitInv<REGTW>& S, const uint2* twf, u32 t) {
     S.t = t;
     S.a0 = phys(4 * t);
+    const u32 wb = 48u * (t >> 6);               // e0 = phys + 48 per wave block: 272 w -> 320 w
+    S.x0 = S.a0 + wb;
     const u32 pb1 = ((t >> 2) << 4) | (t & 3u), pb2 = ((t >> 4) << 6) | (t & 15u), pb3 = ((t >> 6) << 8) | (t & 63u);
-    S.l1 = phys(pb1); S.s1 = xlay1(pb1);
+    S.l1 = phys(pb1) + wb; S.s1 = xlay1(pb1);
     S.l2 = xlay1(pb2); S.s2 = xlay2(pb2);
-    S.l3 = xlay2(pb3); S.s3 = pb3;
+    S.l3 = xlay2(pb3); S.s3 = 320u * (t >> 6) + (t & 63u);
     // stage B (block m = 2^(9-B)) uses -tw[m + (m-1-i)], i = position >> (B+1); the sign sits in the operand
     const u32 u0 = t, u1 = t >> 2, u2 = t >> 4, u3 = t >> 6;
     if constexpr (REGTW) {
@@ -897,17 +913,18 @@ __device__ __forceinline__ void split_pass0(const SplitInv<REGTW>& S, const uint
     uint2 fa, fb, fc;
     split_tw<REGTW, 0>(S, twf, fa, fb, fc);
     inv_pass4(a, fa, fb, fc, Q, mu32);
-    *reinterpret_cast<uint4*>(xa + S.a0) = make_uint4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<uint4*>(xa + S.x0) = make_uint4(a[0], a[1], a[2], a[3]);
 }
-// Passes 1..4: xa holds pass 0's output (a workgroup barrier after its stores is the caller's); xa / xb are the
-// ping-pong exchange buffers (1280 words each).  Leaves coefficient j = (r << 8) | t in x[r], in [0, Q).
-// Contains 3 workgroup barriers.
+// Passes 1..4: xa holds pass 0's output, written by this thread's own quad (no barrier needed in between); xa / xb
+// are the ping-pong exchange buffers (1280 words each).  Leaves coefficient j = (r << 8) | t in x[r], in [0, Q).
+// Contains ONE workgroup barrier (before the last pass); the other exchanges are wave-local.
 // at_pass(integral_constant<int, k>) is called at the start of pass k = 1..4 (the kernel spreads its key-row
 // requests over the passes with it: 16 back-to-back 1-KiB loads per wave would block on the memory queue).
 template <bool REGTW, typename F>
 __device__ __forceinline__ void split_inverse_rest(const SplitInv<REGTW>& S, const uint2* twf, u32* xa, u32* xb, u32 Q, u32 mu32,
                                                    uint2 ninv, uint2 wlast, u32 (&x)[4], F&& at_pass) {
     uint2 fa, fb, fc;
+    wave_sync();   // pass 0's stores (this thread's quad) before the loads below
     at_pass(std::integral_constant<int, 1>{});
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = xa[S.l1 + 4 * r];
@@ -915,7 +932,7 @@ __device__ __forceinline__ void split_inverse_rest(const SplitInv<REGTW>& S, con
     inv_pass4(x, fa, fb, fc, Q, mu32);
 #pragma unroll
     for (int r = 0; r < 4; ++r) xb[S.s1 + 4 * r] = x[r];
-    block_sync_lds();
+    wave_local_sync();
     at_pass(std::integral_constant<int, 2>{});
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = xb[S.l2 + 20 * r];
@@ -923,7 +940,7 @@ __device__ __forceinline__ void split_inverse_rest(const SplitInv<REGTW>& S, con
     inv_pass4(x, fa, fb, fc, Q, mu32);
 #pragma unroll
     for (int r = 0; r < 4; ++r) xa[S.s2 + 16 * r] = x[r];
-    block_sync_lds();
+    wave_local_sync();
     at_pass(std::integral_constant<int, 3>{});
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = xa[S.l3 + 80 * r];
@@ -934,7 +951,7 @@ __device__ __forceinline__ void split_inverse_rest(const SplitInv<REGTW>& S, con
     block_sync_lds();
     at_pass(std::integral_constant<int, 4>{});
 #pragma unroll
-    for (int r = 0; r < 4; ++r) x[r] = xb[S.t + 256 * r];
+    for (int r = 0; r < 4; ++r) x[r] = xb[S.t + 320 * r];
     if constexpr (REGTW) inv_pass4_last(x, S.fa[4], S.fb[4], ninv, wlast, Q);
     else inv_pass4_last(x, twf[tw_pos<2>(1)], twf[tw_pos<2>(0)], ninv, wlast, Q);
 }
@@ -1092,7 +1109,6 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
         u32 a[4] = {v.x, v.y, v.z, v.w};
         split_pass0(S, twf, a, xa, Q, P.mu32);
     }
-    block_sync_lds();
 
     BCE_PROF_INIT();
     const u32 nsteps = AP ? n * P.dR : n;
@@ -1192,7 +1208,10 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
             split_pass0(S, twf, anew, xa, Q, P.mu32);  // mc == c, mp0 == 4 t: this thread's pass-0 registers
         }
         BCE_PROF_MARK(4);
-        block_sync_lds();
+        // no barrier here: the next step's passes 1..3 touch only this wave's own words of xa / xb, and its first
+        // cross-wave access (pass 4, then the digit rows) sits behind the barrier inside split_inverse_rest, which
+        // every wave reaches only after its MAC reads of the digit rows
+        wave_local_sync();
         BCE_PROF_MARK(5);
     }
     // accumulator back to COEFFICIENT form for the extraction kernel (its pass 0 is already in xa)
