@@ -35,7 +35,7 @@ namespace bce {
 
 #include "phase_prof.hpp"
 #ifdef BCE_PHASE_PROF
-__device__ unsigned long long g_phase_prof[8];
+__device__ unsigned long long g_phase_prof[BCE_PROF_WAVES * BCE_PROF_SLOTS];
 #define BCE_PROF_ARRAY ::bce::g_phase_prof
 #endif
 
@@ -793,6 +793,7 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
         __syncthreads();
         BCE_PROF_MARK(5);
     }
+    BCE_PROF_FLUSH();
 
     // accumulator back to COEFFICIENT form for the extraction kernel
     if (wave < 2) {
@@ -1134,6 +1135,7 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
         uint4 kA[R], kB[R];
         auto request_rows = [&](auto kc) {
             constexpr u32 k = decltype(kc)::value - 1, G = PR / 4;  // pass k+1 requests rows [k*G, (k+1)*G) of each key
+            BCE_PROF_MARK(8 + k);   // 8: step head, 9: pass 1, 10: pass 2, 11: pass 3 + the barrier; slot 0 is then pass 4 + digits
 #pragma unroll
             for (u32 l = k * G; l < (k + 1) * G; ++l) {
                 kA[l] = bsk_row(rsrc, tid * 16u, rowb + l * (2 * N * 4));
@@ -1214,6 +1216,7 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
         wave_local_sync();
         BCE_PROF_MARK(5);
     }
+    BCE_PROF_FLUSH();
     // accumulator back to COEFFICIENT form for the extraction kernel (its pass 0 is already in xa)
     {
         u32 x[4];
@@ -1611,9 +1614,9 @@ hipError_t launch_pointwise_mac(const DevParams& P, u32* b, const u32* a, const 
 
 #ifdef BCE_PHASE_PROF
 extern "C" int bce_debug_phase_prof(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bce::g_phase_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bce::g_phase_prof), sizeof(unsigned long long) * 256) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[8] = {0};
+        unsigned long long z[256] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(bce::g_phase_prof), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;

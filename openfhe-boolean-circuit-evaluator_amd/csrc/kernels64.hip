@@ -17,7 +17,7 @@
 
 namespace bce {
 #ifdef BCE_PHASE_PROF
-__device__ unsigned long long g_phase_prof64[8];
+__device__ unsigned long long g_phase_prof64[BCE_PROF_WAVES * BCE_PROF_SLOTS];
 #define BCE_PROF_ARRAY ::bce::g_phase_prof64
 #endif
 namespace w64 {
@@ -411,6 +411,7 @@ __global__ __launch_bounds__(128 * DG) void k_blind_rotate64(DevParams P, const 
         block_sync_lds();
         BCE_PROF_MARK(5);
     }
+    BCE_PROF_FLUSH();
     if (wave < 2) {
         u64 x[E];
         ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, tw, lane, Q, ninv, x);
@@ -490,6 +491,15 @@ using w64::phys;
 using w64::elem_j;
 using w64::wave_sync;
 using w64::block_sync_lds;
+// exchange of the split inverse transform that stays inside one wave; -DBCE_STEP_BARRIERS = the workgroup barriers of
+// the earlier schedule (A/B runs)
+#ifdef BCE_STEP_BARRIERS
+constexpr int INV_BARRIERS = 3;
+__device__ __forceinline__ void wave_local_sync() { block_sync_lds(); }
+#else
+constexpr int INV_BARRIERS = 1;
+__device__ __forceinline__ void wave_local_sync() { wave_sync(); }
+#endif
 using w64::for_each_index;
 using w64::gate_const;
 
@@ -772,7 +782,11 @@ __device__ __forceinline__ double2 key_row(__amdgpu_buffer_rsrc_t rsrc, u32 voff
 // Three-stage passes on position bits (0,1,2), (3,4,5), (6,7,8) and a two-stage pass on (9,10); between passes the
 // values go through LDS in REGISTER-MAJOR layouts (register r of thread t at r * stride + t: consecutive lanes,
 // conflict-free stores) whose row strides make the next pass's loads conflict-free too:
-//   e0: 257 (reader lanes vary p[2:0] and p[8:6]),  e1: 264 (reader lanes vary p[5:0]),  e2: 256.
+//   e0: 257 (reader lanes vary p[2:0] and p[8:6]),  e1: 264 (reader lanes vary p[5:0]),  e2: 257 (any stride is
+//   conflict-free for it; 257 makes a wave's e2 words the same set as its e0 words).
+// The exchanges after passes 0 and 1 swap register bits with LANE bits only (pass 1 reads what its own wave's pass 0
+// wrote, pass 2 what its own wave's pass 1 wrote) and every wave's words in a buffer are the same set in every layout:
+// they need no workgroup barrier.  Only the exchange before the last pass (position bits 10:9 <-> wave) crosses waves.
 // No reduction anywhere (see the bounds above); the caller multiplies by N^-1.
 // three Gentleman-Sande stages on the register index bits 0,1,2; twiddles: f0[4] (bit 0), f1[2] (bit 1), f2 (bit 2)
 __device__ __forceinline__ void inv_pass8(double (&x)[8], const double2 (&f0)[4], const double2 (&f1)[2], double2 f2, double Q) {
@@ -803,8 +817,8 @@ __device__ __forceinline__ double2 itw11(Tw tw, u32 i) {
     return tw.blk<m, 1024>()[(2 * m - 1) - i];
 }
 // acc: evaluation-form polynomial (padded natural layout); bufA / bufB: >= 2112 doubles each; t = thread in the
-// 256-thread group.  Leaves coefficient j = (r << 8) | t in x[r] (before the N^-1 scaling).  4 workgroup barriers;
-// bufA must not be written by anyone until the caller's next barrier (pass 3 reads it).
+// 256-thread group.  Leaves coefficient j = (r << 8) | t in x[r] (before the N^-1 scaling).  INV_BARRIERS workgroup
+// barriers; bufA must not be written by anyone until the caller's next barrier (pass 3 reads it).
 __device__ __forceinline__ void split_inverse11(const double* src, double* bufA, double* bufB, Tw tw, u32 t, double Q,
                                                 double (&x)[8]) {
     double2 f0[4], f1[2], f2;
@@ -820,7 +834,7 @@ __device__ __forceinline__ void split_inverse11(const double* src, double* bufA,
 #pragma unroll
         for (int r = 0; r < 8; ++r) bufA[r * 257 + t] = x[r];          // e0
     }
-    block_sync_lds();
+    wave_local_sync();
     {   // pass 1: p = (g << 6) | (r << 3) | l,  g = t >> 3, l = t & 7; e0 address of p: (p & 7) * 257 + (p >> 3)
         const u32 g = t >> 3, l = t & 7u;
 #pragma unroll
@@ -833,7 +847,7 @@ __device__ __forceinline__ void split_inverse11(const double* src, double* bufA,
 #pragma unroll
         for (int r = 0; r < 8; ++r) bufB[r * 264 + t] = x[r];          // e1 (t = (g << 3) | l)
     }
-    block_sync_lds();
+    wave_local_sync();
     {   // pass 2: p = (h << 9) | (r << 6) | m,  h = t >> 6, m = t & 63; e1 address of p: p[5:3] * 264 + ((p >> 6) << 3 | p[2:0])
         const u32 h = t >> 6, m = t & 63u;
 #pragma unroll
@@ -844,12 +858,12 @@ __device__ __forceinline__ void split_inverse11(const double* src, double* bufA,
         f2 = itw11<8>(tw, h);
         inv_pass8(x, f0, f1, f2, Q);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) bufA[r * 256 + t] = x[r];          // e2 (t = (h << 6) | m)
+        for (int r = 0; r < 8; ++r) bufA[r * 257 + t] = x[r];          // e2 (t = (h << 6) | m)
     }
     block_sync_lds();
-    {   // pass 3: p = (r << 8) | t; e2 address of p: p[8:6] * 256 + (p[10:9] << 6 | p[5:0]); stages on bits 9, 10
+    {   // pass 3: p = (r << 8) | t; e2 address of p: p[8:6] * 257 + (p[10:9] << 6 | p[5:0]); stages on bits 9, 10
 #pragma unroll
-        for (int r = 0; r < 8; ++r) x[r] = bufA[((((u32)r & 1u) << 2) | (t >> 6)) * 256 + ((((u32)r >> 1) << 6) | (t & 63u))];
+        for (int r = 0; r < 8; ++r) x[r] = bufA[((((u32)r & 1u) << 2) | (t >> 6)) * 257 + ((((u32)r >> 1) << 6) | (t & 63u))];
         const double2 g0 = itw11<9>(tw, 0), g1 = itw11<9>(tw, 1), g2 = itw11<10>(tw, 0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {  // bit 9 = register bit 1: pairs (r, r+2), r in {0,1,4,5}; stage index = r >> 2
@@ -1007,7 +1021,8 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
         if constexpr (NPRE >= 2) request(std::integral_constant<u32, 1>{});
         if (W16 && tid_v >= 512u) {
             // waves 8..15 have no share of the inverse transforms: they only keep the barrier count
-            block_sync_lds(); block_sync_lds(); block_sync_lds(); block_sync_lds();
+#pragma unroll
+            for (int b = 0; b < INV_BARRIERS + 1; ++b) block_sync_lds();
         } else if constexpr (SPLIT) {
             const u32 c = wave >> 2, t = tid_v & 255u;
             double x[8];
@@ -1145,8 +1160,10 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
         block_sync_lds();
         BCE_PROF_MARK(5);
     }
+    BCE_PROF_FLUSH();
     if (W16 && tid >= 512u) {
-        block_sync_lds(); block_sync_lds(); block_sync_lds();
+#pragma unroll
+        for (int b = 0; b < INV_BARRIERS; ++b) block_sync_lds();
     } else if constexpr (SPLIT) {
         const u32 c = wave >> 2, t = tid & 255u;
         double x[8];
@@ -1277,9 +1294,9 @@ hipError_t launch_pointwise_mac64(const DevParams& P, u64* b, const u64* a, cons
 
 #ifdef BCE_PHASE_PROF
 extern "C" int bce_debug_phase_prof64(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bce::g_phase_prof64), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bce::g_phase_prof64), sizeof(unsigned long long) * 256) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[8] = {0};
+        unsigned long long z[256] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(bce::g_phase_prof64), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;

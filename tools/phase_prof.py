@@ -35,7 +35,7 @@ def main():
     c.pool_reserve(3 * nmax)
     bits = np.random.default_rng(0).integers(0, 2, size=2 * nmax).astype(np.uint8)
     c.Encrypt(bits, np.arange(2 * nmax), enc_index_base=0)
-    out = (C.c_ulonglong * 8)()
+    out = (C.c_ulonglong * 256)()
     for nb in batches:
         descs = bce.make_descs([(bce.NAND, 2 * i, 2 * i + 1, 2 * nmax + i) for i in range(nb)])
         c.EvalGates(descs)
@@ -46,10 +46,17 @@ def main():
         c.synchronize()
         getter(out, 1)
         t = c.timing()
-        tot = float(sum(out[:6]))
-        print("batch %d: blind_rotate %.2f ms, workgroup 0 total %.0f cycles" % (nb, t["blind_rotate_ms"], tot))
-        for k, name in enumerate(NAMES):
-            print("   %-56s %10d cycles  %5.1f%%" % (name, out[k], 100.0 * out[k] / tot))
+        print("batch %d: blind_rotate %.2f ms; workgroup 0, cycles per wave (rows) and phase (columns), wave 0 total %.0f" % (
+            nb, t["blind_rotate_ms"], float(sum(out[:16]))))
+        cols = [8, 9, 10, 11, 0, 1, 2, 3, 4, 5] if ps == "STD128_OPT" else [0, 1, 2, 3, 4, 5]
+        names = {8: "head", 9: "inv p1", 10: "inv p2", 11: "p3+bar", 0: "phase1" if ps != "STD128_OPT" else "p4+digits", 1: "wait b1", 2: "forward", 3: "wait b2", 4: "MAC", 5: "wait b3"}
+        print("   wave " + " ".join("%10s" % names[k] for k in cols) + "      total")
+        for w in range(16):
+            row = out[16 * w:16 * w + 16]
+            if not any(row):
+                continue
+            print("   %4d " % w + " ".join("%10d" % row[k] for k in cols) + " %10d" % sum(row))
+
 
 
 main()
