@@ -125,6 +125,8 @@ def main():
     ap.set_defaults(relevel=True)
     ap.add_argument("--xor-fast", action="store_true", help="opt-in native XOR (NOT the reference's XOR = 3 bootstraps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-block-latency", action="store_true",
+                    help="skip the K = 1 single-block leg (profiled runs: keeps the kernel statistics to the timed workload)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--gates-timeout", type=int, default=150, help="N > 1: watchdog (s) over the secondary run and the teardown")
     ap.add_argument("--gates-steps", type=int, default=2, help="N > 1: timed steps of the secondary gate-sharded run (0 = skip)")
@@ -285,7 +287,7 @@ def main():
         dt = time.time() - t0
         c1.close()
         return dt
-    block_latency_s = single_block_latency()
+    block_latency_s = None if args.no_block_latency else single_block_latency()
     G = G_err = None
     out = None
     elapsed, total_boot, verified, tm, info = R["elapsed"], R["total_boot"], R["verified"], R["tm"], R["info"]
@@ -385,7 +387,7 @@ def main():
                 "xor": "XOR_FAST (opt-in, 1 bootstrap)" if args.xor_fast else "NOT,NOT,AND,AND,OR (reference, 3 bootstraps)",
                 "bootstraps_per_step": int(total_boot / args.steps),
                 "gates_per_s": (info["n_gates"] - info["n_output_bits"]) * args.instances * world * args.steps / elapsed,
-                "single_block_latency_s": round(block_latency_s, 4),
+                "single_block_latency_s": None if block_latency_s is None else round(block_latency_s, 4),
                 "outputs_verified": bool(verified), "setup_s": round(setup_s, 2), "keygen_s": round(keygen_s, 3),
                 "host_share_of_step": round(1.0 - (tm["blind_rotate_ms"] + tm["tail_ms"]) / (elapsed * 1e3), 4),
                 "exchanges_per_step": R["exchanges_per_step"], "exchanged_cts_per_step": R["exchanged_cts_per_step"],

@@ -16,7 +16,7 @@ if [ "$2" != "profile-only" ]; then
 fi
 export TMPDIR=/tmp
 cd /tmp
-BENCH1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
+BENCH1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-block-latency"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH1 > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof_stats.err"
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_kernel_stats.csv"
 head -5 "$OUT/bench_kernel_stats.csv"

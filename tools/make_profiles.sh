@@ -25,7 +25,7 @@ out = {"kernel": br, "bench_kernel": label,
        "fetch_kib_raw_per_launch": raw[br]["fetch_kib_raw_per_launch"], "write_kib_per_launch": raw[br]["write_kib_per_launch"],
        "tail_hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] for v in tails.values()),
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 1 --warmup 0 "
-                 "--no-cpu-baseline` (tools/collect_evidence.sh); FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as is; "
+                 "--no-cpu-baseline --no-block-latency` (tools/collect_evidence.sh); FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as is; "
                  "KiB -> bytes; Infinity-Cache hits are included in these fabric-side counters",
        "tail_kernels": tails}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
