@@ -22,15 +22,16 @@ m = json.load(open("%s/%s_cfg5_valu_model.json" % (P, PRE)))
 t = json.load(open("%s/%s_cfg5_pmc_traffic.json" % (P, PRE)))
 rows = [r for r in csv.DictReader(open("%s/%s_cfg5_kernel_stats.csv" % (P, PRE))) if "k_blind_rotate64d" in r["Name"]]
 r = max(rows, key=lambda r: float(r["TotalDurationNs"]))
-# quick_perf_cfg runs 1 warm-up + 3 timed launches of 256 bootstraps: MinNs..MaxNs bracket them, AverageNs is their mean
-launch_ms = float(r["AverageNs"]) / 1e6
+# quick_perf_cfg runs one warm-up launch (cold key) and one timed launch of 256 bootstraps: the timed one is MinNs, and it
+# is the dispatch the PMC passes read (pmc_sq_summary.py / pmc_one_launch.py take the LAST dispatch)
+launch_ms = float(r["MinNs"]) / 1e6
 boots = m["pmc_launch_bootstraps"]
 floor_ms = m["valu_insts_per_bootstrap"] * boots * m["ns_per_wave_inst_per_simd"] / (4 * 256) / 1e6
 # algorithmic bytes per bootstrap: the engine's own figure (bce_bytes_per_bootstrap, SURVEY 8(d) formula at this build's
 # widths: n*dR steps x one RGSW key of 2*dG rows x 2 polynomials x N doubles, + KSK rows + ciphertext I/O)
 import re
 alg = int(re.search(r"bytes/bootstrap (\d+)", open("%s/%s_cfg5_quick_perf.log" % (P, PRE)).read()).group(1))
-out = {"kernel": r["Name"].split("(")[0], "bootstraps_per_launch": boots, "launches_in_stats": int(r["Calls"]), "avg_launch_ms": launch_ms,
+out = {"kernel": r["Name"].split("(")[0], "bootstraps_per_launch": boots, "launches_in_stats": int(r["Calls"]), "launch_ms": launch_ms, "launch_ms_is": "MinNs of the kernel-stats row = the timed (second) launch",
        "valu": {"insts_per_bootstrap": m["valu_insts_per_bootstrap"], "ns_per_wave_inst_per_simd": m["ns_per_wave_inst_per_simd"],
                 "floor_ms_per_launch": floor_ms, "frac": floor_ms / launch_ms,
                 "note": "fp64 FMA/mul/add/rndne at 4.2 cycles per wave-instruction (profiles/%s_valu_issue.jsonl); mix of the step loop in %s_cfg5_valu_model.json" % (PRE, PRE)},
