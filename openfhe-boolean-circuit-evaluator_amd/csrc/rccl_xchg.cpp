@@ -50,7 +50,11 @@ Rccl& rccl() {
             x.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (x.handle) break;
         }
-        if (!x.handle) { x.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return x; }
+        if (!x.handle) {
+            const char* e = dlerror();   // one call: dlerror() clears the message it returns
+            x.why = std::string("RCCL not found: ") + (e ? e : "dlopen failed");
+            return x;
+        }
         x.get_unique_id = (GetUniqueIdFn)dlsym(x.handle, "ncclGetUniqueId");
         x.comm_init_rank = (CommInitRankFn)dlsym(x.handle, "ncclCommInitRank");
         x.comm_destroy = (CommDestroyFn)dlsym(x.handle, "ncclCommDestroy");
