@@ -156,6 +156,46 @@ def test_aes_expanded_std128_full_circuit(bce, std_cc):
     assert c.stats()["bootstraps"] == 66415 * len(vecs)
 
 
+def test_aes_non_expanded_std128_both_vectors(bce, std_cc):
+    """The reference's other AES netlist (src/test_aes.cpp:201-228: 33,616 gates, key schedule inside the circuit,
+    82,172 bootstraps -- the "~34k gates" BASELINE.json quotes), both vectors in lock-step"""
+    c = bce.Circuit(std_cc)
+    c.ReadBristol(os.path.join(CIRCUITS, "AES-non-expanded.txt"))
+    vecs = [v for v in kat.AES_VECTORS if v["circuit"] == "AES-non-expanded"]
+    assert len(vecs) == 2
+    c.setInstances(len(vecs))
+    c.Reset()
+    c.setEncrypted(True)
+    for k, v in enumerate(vecs):
+        c.SetInput(kat.aes_case(v)[0], instance=k)
+    c.Clock()
+    for k, v in enumerate(vecs):
+        assert c.Outputs(k)[0] == kat.aes_case(v)[1]
+    assert c.stats()["bootstraps"] == 82172 * len(vecs)
+
+
+def test_md5_std128_four_vectors_in_lock_step(bce, std_cc):
+    """src/test_md5.cpp: md5.txt (77,989 gates, 71,534 bootstraps, 6,161 levels of at most 21 gates -- the deepest and
+    narrowest circuit of the corpus), the four vectors of md5-test.txt as K = 4 lock-step instances on the
+    bootstrap-depth schedule (3,852 dependent launches instead of 11,974)."""
+    c = bce.Circuit(std_cc)
+    c.ReadBristol(os.path.join(CIRCUITS, "md5.txt"))
+    c.setRelevel(True)
+    vecs = kat.hash_vectors("md5-test.txt")
+    assert len(vecs) == 4
+    c.setInstances(len(vecs))
+    c.Reset()
+    c.setEncrypted(True)
+    for k, (inhex, outhex) in enumerate(vecs):
+        c.SetInput(kat.md5_case(inhex, outhex)[0], instance=k)
+    c.Clock()
+    for k, (inhex, outhex) in enumerate(vecs):
+        assert c.Outputs(k)[0] == kat.md5_case(inhex, outhex)[1], "md5 vector %d" % k
+    st = c.stats()
+    assert st["bootstraps"] == 71534 * len(vecs)
+    print("md5 x%d: %.1f s, %d dependent launches" % (len(vecs), st["total_ms"] / 1e3, st["sublaunches"]))
+
+
 def test_sha256_new_format_std128_four_vectors_in_lock_step(bce, std_cc):
     """BASELINE config 4: new-format sha256 (135,073 gates, 354,505 bootstraps, 5,332 levels), the four
     reference vectors of sha-256-test.txt evaluated as K = 4 lock-step instances (1.4 M bootstraps)."""
