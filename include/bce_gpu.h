@@ -175,6 +175,10 @@ uint64_t bce_bytes_per_bootstrap(const bce_ctx*);
 /* the same figure split by the kernel that moves the bytes: out[0] = bootstrapping-key rows (blind rotation),
  * out[1] = key-switching-key rows (tail gather), out[2] = ciphertext input / output words */
 int bce_bytes_per_bootstrap_parts(const bce_ctx*, uint64_t out[3]);
+/* forward transforms one AddToAcc step runs: 2 dG as in the reference (rgsw-acc-cggi.cpp / rgsw-acc-dm.cpp AddToAcc),
+ * or 2 dG - 2 when this context keeps its key with the lowest gadget digit folded in (same accumulator words; the
+ * decomposition is exact for the parameter set and the digit-0 rows multiply the accumulator itself) */
+uint32_t bce_forward_transforms_per_step(const bce_ctx*);
 
 /* ---- in-library collective (multi-GPU, one process per GPU) ---------------------------------------------
  * RCCL all-gather issued on the engine's own stream, so that the exchange of boundary ciphertexts between two

@@ -57,7 +57,7 @@ ENGINE_SYMBOLS = [
     "bce_keygen", "bce_import_keys", "bce_import_keys_file", "bce_export_keys_file", "bce_bsk_words", "bce_ksk_words", "bce_export_sk", "bce_export_bsk",
     "bce_export_ksk", "bce_pool_reserve", "bce_pool_slots", "bce_lwe_write", "bce_lwe_read",
     "bce_encrypt_bits", "bce_set_encrypt_seed", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize",
-    "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_rccl_available", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
+    "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_forward_transforms_per_step", "bce_rccl_available", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
     "bce_rccl_shutdown", "bce_debug_eval_stages", "bce_debug_ntt",
 ]
 
@@ -113,6 +113,8 @@ def lib():
     L.bce_bytes_per_bootstrap.argtypes = [vp]
     L.bce_bytes_per_bootstrap.restype = u64
     L.bce_bytes_per_bootstrap_parts.argtypes = [vp, C.POINTER(u64)]
+    L.bce_forward_transforms_per_step.argtypes = [vp]
+    L.bce_forward_transforms_per_step.restype = C.c_uint32
     L.bce_rccl_unique_id.argtypes = [C.c_char_p]
     L.bce_rccl_init.argtypes = [vp, C.c_char_p, i32, i32]
     L.bce_rccl_allgather.argtypes = [vp, vp, vp, u64]
@@ -303,6 +305,9 @@ class BinFHEContext:
         buf = (C.c_uint64 * 3)()
         self._ck(self._L.bce_bytes_per_bootstrap_parts(self.h, buf))
         return {"bsk": int(buf[0]), "ksk": int(buf[1]), "ct": int(buf[2])}
+
+    def forward_transforms_per_step(self):
+        return int(self._L.bce_forward_transforms_per_step(self.h))
 
     # --- staged outputs for parity ---
     def debug_eval_stages(self, descs):

@@ -245,6 +245,21 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         P.cu_count = (u32)cus;
         const char* ft = std::getenv("BCE_FUSE_TAIL");  // development / parity knob: 0 keeps the separate tail kernels
         P.fuse_tail = (ft && ft[0] == '0') ? 0 : 1;
+        // Lowest gadget digit folded into the key (kernels.hip, FOLD): needs a kernel that has the variant and an EXACT
+        // SignedDigitDecompose -- every centred residue d in [-(Q - Q/2), Q/2) must equal sum_l r_l B^l with dG digits
+        // r_l in [-B/2, B/2) (then the carry the reference drops after the last digit is always zero).  TOY (27-bit Q,
+        // B = 2^9, 3 digits) fails it for the top 0.1 % of residues; STD128* (B = 2^7, 4 digits) and STD192* (37-bit Q,
+        // B = 2^13, 3 digits) pass.  BCE_FOLD=0 keeps the plain key (development / parity knob).
+        {
+            const u128 Bg = (u128)1 << c->gBits;
+            u128 span = 0, pw = 1;
+            for (u32 l = 0; l < c->dG; ++l) { span += pw; pw *= Bg; }
+            const u128 hi = (Bg / 2 - 1) * span, lo = (Bg / 2) * span;       // largest / smallest (negated) representable value
+            const bool exact = (u128)(Q >> 1) <= hi + 1 && (u128)(Q - (Q >> 1)) <= lo;
+            const bool has_kernel = !c->is64 && c->logN == 10 && c->dG == 4 && P.lazy && P.variant != 1;
+            const char* fo = std::getenv("BCE_FOLD");
+            P.fold = (exact && has_kernel && !(fo && fo[0] == '0')) ? 1 : 0;
+        }
     }
     {
         u64 I = pow_mod(c->psi, N / 2, Q), v = 1;
@@ -299,9 +314,12 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     return BCE_OK;
 }
 
-// the double-precision 64-bit kernels read the evaluation-form key words as IEEE doubles (exact, Q < 2^39)
+u64 rgsw_rows_total(const bce_ctx* c);
+// evaluation-form key words -> what the kernels read: rows l >= 1 of every RGSW ciphertext minus B^l times row 0
+// when the lowest gadget digit is folded (P.fold); IEEE doubles for the double-precision 64-bit kernels (exact, Q < 2^39)
 int bsk_words_to_kernel_layout(bce_ctx* c) {
-    if (!c->is64 || !c->P.fp64) return BCE_OK;
+    if (c->P.fold) HIP_TRY(c, launch_fold_gadget(c->P, c->d_bsk, rgsw_rows_total(c) / (2ull * c->dG), +1, c->stream));
+    if (!c->is64 || !c->P.fp64) { HIP_TRY(c, hipStreamSynchronize(c->stream)); return BCE_OK; }
     HIP_TRY(c, launch_words_u64_f64(static_cast<u64*>(c->d_bsk), (size_t)c->bsk_polys * c->N, 1, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return BCE_OK;
@@ -718,7 +736,8 @@ int bce_export_bsk(bce_ctx* c, uint64_t* bsk) {
     if (!c->have_keys) return c->fail(BCE_ERR_NO_KEYS, "no keys");
     HIP_TRY(c, hipSetDevice(c->device));
     const u64 words = bce_bsk_words(c);
-    const u64 chunk_polys = std::max<u64>(1, ((u64)256 << 20) / ((u64)c->N * c->wbytes));
+    const u64 per_rgsw = 4ull * c->dG;  // polynomials of one RGSW ciphertext: chunks hold whole ciphertexts (un-folding works per ciphertext)
+    const u64 chunk_polys = std::max<u64>(1, ((u64)256 << 20) / ((u64)c->N * c->wbytes) / per_rgsw) * per_rgsw;
     void* d_tmp = nullptr;
     HIP_TRY(c, hipMalloc(&d_tmp, chunk_polys * c->N * c->wbytes));
     struct Free { void* p; ~Free() { hipFree(p); } } free_tmp{d_tmp};  // released on every return path
@@ -728,6 +747,7 @@ int bce_export_bsk(bce_ctx* c, uint64_t* bsk) {
         const char* src = static_cast<const char*>(c->d_bsk) + p0 * c->N * c->wbytes;
         HIP_TRY(c, hipMemcpyAsync(d_tmp, src, w * c->wbytes, hipMemcpyDeviceToDevice, c->stream));
         if (c->P.fp64) HIP_TRY(c, launch_words_u64_f64(static_cast<u64*>(d_tmp), w, 0, c->stream));  // doubles -> u64 words
+        if (c->P.fold) HIP_TRY(c, launch_fold_gadget(c->P, d_tmp, cnt / (4ull * c->dG), -1, c->stream));   // rows l >= 1 += B^l row 0
         int rc = dev_ntt(c, d_tmp, cnt, 1);
         if (rc) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -935,6 +955,8 @@ int bce_timing_get(bce_ctx* c, bce_timing* out) {
     *out = c->timing;
     return BCE_OK;
 }
+
+uint32_t bce_forward_transforms_per_step(const bce_ctx* c) { return c ? 2 * c->dG - (c->P.fold ? 2 : 0) : 0; }
 
 int bce_bytes_per_bootstrap_parts(const bce_ctx* c, uint64_t out[3]) {
     if (!c || !out) return BCE_ERR_ARG;

@@ -440,6 +440,85 @@ __device__ __forceinline__ void ntt_forward_wave_low8(u32* poly, const uint2* tw
     store_pass<LOGN, 0>(poly, lane, x);
     wave_sync();
 }
+// The same eight stages on ONE HALF of such a row: positions [512 h, 512 h + 512) are two of the four independent
+// 256-point sub-transforms left after the stages on bits 9 and 8.  64 lanes x 8 register pairs, three passes (bits
+// 7..5, 4..2, 1..0), two wave-local re-shuffles, in place: half the butterflies of ntt_forward_wave_low8 with every
+// lane busy.  The FOLD kernel transforms six rows per step with it: four whole rows on waves 0..3, two rows as four
+// halves on waves 4..7 -- 1.5 transforms on every SIMD.
+__device__ __forceinline__ void fwd_bfly_pair(u64& xa, u64& xb, uint2 w, u32 Q) {
+    const u32 X = (u32)xa, Y = (u32)xb;
+    const u64 t = mad64(__umulhi(Y, w.y), 0u - Q, mad64(Y, w.x, xa));
+    xb = with_lo(xb, (X << 1) + 2 * Q - (u32)t);
+    xa = t;
+}
+__device__ __forceinline__ void ntt_forward_half_low8(u32* row, u32 h, const uint2* twf, u32 lane, u32 Q) {
+    // the lane-dependent LDS addresses below are a few shifts and adds each; opaque to the optimiser, so that they are
+    // recomputed per call instead of living in ~10 registers across the caller's step loop (the 128-register build
+    // spilled them, and a scratch reload waits on vmcnt(0), i.e. on the key rows in flight)
+    asm volatile("" : "+v"(lane));
+    u64 xp[8];
+    {   // registers = bits 7..5, lane = (bit 8, bits 4..0)
+        const u32 l8 = lane >> 5, j0 = (h << 9) | (l8 << 8) | (lane & 31u);
+        u32* const p = row + phys(j0);               // register r: j0 + 32 r, same 64-block for r, r + 1
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xp[r] = pair_of(p[(r >> 1) * 68 + (r & 1) * 32]);
+        const u32 i7 = (h << 1) | l8;                // stage on bit B: twiddle tw[m + (j >> (B + 1))], m = 2^(9 - B)
+        const uint2 w7 = twf[tw_pos<4>(i7)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fwd_bfly_pair(xp[r], xp[r + 4], w7, Q);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint2 w6 = twf[tw_pos<8>((i7 << 1) | g)];
+            fwd_bfly_pair(xp[4 * g], xp[4 * g + 2], w6, Q);
+            fwd_bfly_pair(xp[4 * g + 1], xp[4 * g + 3], w6, Q);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fwd_bfly_pair(xp[2 * g], xp[2 * g + 1], twf[tw_pos<16>((i7 << 2) | g)], Q);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) p[(r >> 1) * 68 + (r & 1) * 32] = (u32)xp[r];
+    }
+    wave_sync();
+    {   // registers = bits 4..2, lane = (bits 8..5, bits 1..0)
+        const u32 lh = lane >> 2, j0 = (h << 9) | (lh << 5) | (lane & 3u);
+        u32* const p = row + phys(j0);               // register r: j0 + 4 r, inside one 64-block
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xp[r] = pair_of(p[4 * r]);
+        const u32 i4 = (h << 4) | lh;
+        const uint2 w4 = twf[tw_pos<32>(i4)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fwd_bfly_pair(xp[r], xp[r + 4], w4, Q);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint2 w3 = twf[tw_pos<64>((i4 << 1) | g)];
+            fwd_bfly_pair(xp[4 * g], xp[4 * g + 2], w3, Q);
+            fwd_bfly_pair(xp[4 * g + 1], xp[4 * g + 3], w3, Q);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fwd_bfly_pair(xp[2 * g], xp[2 * g + 1], twf[tw_pos<128>((i4 << 2) | g)], Q);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) p[4 * r] = (u32)xp[r];
+    }
+    wave_sync();
+    {   // registers = bits 2..0 (bit 2 is done): 8 consecutive words per lane
+        const u32 j0 = (h << 9) | (lane << 3);
+        uint4* const p = reinterpret_cast<uint4*>(row + phys(j0));
+        const uint4 v0 = p[0], v1 = p[1];
+        xp[0] = pair_of(v0.x); xp[1] = pair_of(v0.y); xp[2] = pair_of(v0.z); xp[3] = pair_of(v0.w);
+        xp[4] = pair_of(v1.x); xp[5] = pair_of(v1.y); xp[6] = pair_of(v1.z); xp[7] = pair_of(v1.w);
+        const u32 i1 = (((h << 6) | lane) << 1);     // j >> 2 for registers 0..3; + 1 for 4..7
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint2 w1 = twf[tw_pos<256>(i1 | g)];
+            fwd_bfly_pair(xp[4 * g], xp[4 * g + 2], w1, Q);
+            fwd_bfly_pair(xp[4 * g + 1], xp[4 * g + 3], w1, Q);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fwd_bfly_pair(xp[2 * g], xp[2 * g + 1], twf[tw_pos<512>((i1 << 1) | g)], Q);
+        p[0] = make_uint4((u32)xp[0], (u32)xp[1], (u32)xp[2], (u32)xp[3]);
+        p[1] = make_uint4((u32)xp[4], (u32)xp[5], (u32)xp[6], (u32)xp[7]);
+    }
+    wave_sync();
+}
 // one lazy Cooley-Tukey butterfly on plain registers (5 instructions; X' = X + wY, Y' = X - wY + 2Q)
 __device__ __forceinline__ void fwd_bfly(u32& X, u32& Y, uint2 w, u32 Q) {
     const u64 t = mad64(__umulhi(Y, w.y), 0u - Q, mad64(Y, w.x, pair_of(X)));
@@ -510,12 +589,13 @@ __device__ __forceinline__ u32 gate_const(u32 op, u32 q) {
 
 // Tail of one GINX MAC item: sp / sn are the 64-bit row sums against key+ / key- at the 4 consecutive
 // evaluation positions p0..p0+3; multiplies them by the monomials psi^(+-(2k+1)a') - 1 and accumulates
-// into the 4 accumulator words at accp (also returned in a[], values < 2Q when LAZY).
+// into the 4 accumulator words read at accp, written to accw (also returned in a[], values < 2Q when LAZY).
 // I^a' and I^-a' for I = psi^(N/2): the 4 positions sit at evaluation points whose exponents differ by
 // multiples of (N/2)*a' (brv(p0+e) = brv(p0) + {0,2,1,3}*N/4).
 template <int LOGN, bool LAZY>
 __device__ __forceinline__ void ginx_mac_tail(const DevParams& P, __amdgpu_buffer_rsrc_t psi_rsrc, u32 Q, u32 ap, uint2 Ia,
-                                              uint2 Ina, u32 p0, u32* accp, const u64 (&sp)[4], const u64 (&sn)[4], u32 (&a)[4]) {
+                                              uint2 Ina, u32 p0, const u32* accp, u32* accw, const u64 (&sp)[4],
+                                              const u64 (&sn)[4], u32 (&a)[4]) {
     constexpr u32 N = 1u << LOGN;
     const bool odd = ap & 1u;
     const u32 k0 = __brev(p0) >> (32 - LOGN);
@@ -545,7 +625,7 @@ __device__ __forceinline__ void ginx_mac_tail(const DevParams& P, __amdgpu_buffe
             a[e] = barrett_reduce((u64)rp * (mp[e] - 1) + (u64)rn * (mn[e] - 1) + a[e], Q, P.red_shift, P.red_mu);
         }
     }
-    *reinterpret_cast<uint4*>(accp) = make_uint4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<uint4*>(accw) = make_uint4(a[0], a[1], a[2], a[3]);
 }
 
 // Common start of a gate bootstrap: twiddles into LDS, EvalBinGate's LWE preparation (ct1 + ct2 with the
@@ -787,7 +867,7 @@ __global__ __launch_bounds__(128 * DG, (OCC * 2 * DG + 3) / 4) void k_blind_rota
             }
             }
             u32 anew[4];
-            ginx_mac_tail<LOGN, LAZY>(P, psi_rsrc, Q, ap, Ia, Ina, p0, acc + c * NP + pp, sp, sn, anew);
+            ginx_mac_tail<LOGN, LAZY>(P, psi_rsrc, Q, ap, Ia, Ina, p0, acc + c * NP + pp, acc + c * NP + pp, sp, sn, anew);
         }
         BCE_PROF_MARK(4);
         __syncthreads();
@@ -1057,7 +1137,15 @@ __device__ __forceinline__ void fused_tail(const DevParams& P, const u32* coef, 
 // AP = true: AP/DM accumulator -- one step per non-zero base-baseR digit of -a_i, a single RGSW key selected by the
 // digit, the product REPLACES the accumulator (no monomials); everything else is shared with GINX.
 // FUSE: the tail of EvalBinGate (extract, ModSwitch, KeySwitch, ModSwitch) runs in this kernel's epilogue (fused_tail).
-template <int DG, int WPS, bool AP = false, bool FUSE = false>  // WPS = waves per SIMD the register budget allows: 2 (one workgroup per CU) or 4 (two)
+// FOLD: the lowest gadget digit is never transformed.  SignedDigitDecompose is exact for these parameters (the host
+//   checks it: sum_l B^l dct_l = acc as integers), so NTT(dct_0) = ACC - sum_{l>=1} B^l NTT(dct_l) with ACC the
+//   evaluation-form accumulator the kernel already holds, and
+//       sum_l NTT(dct_l) ek_l  =  ACC ek_0 + sum_{l>=1} NTT(dct_l) (ek_l - B^l ek_0)      (mod Q, exactly).
+//   The key arrives with its rows l >= 1 already replaced by ek_l - B^l ek_0 (engine.cpp, k_fold_gadget); the MAC reads
+//   the accumulator rows where the digit-0 rows used to be: 6 forward transforms per step instead of 8, same
+//   accumulator words.  The evaluation-form accumulator is double-buffered between `acc` and the two digit rows that
+//   became free (other threads read a component's words as a MAC row while its owner writes the new ones).
+template <int DG, int WPS, bool AP = false, bool FUSE = false, bool FOLD = false>  // WPS = waves per SIMD the register budget allows: 2 (one workgroup per CU) or 4 (two)
 __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
                                                                    u32 slot_stride, u32* __restrict__ acc_out,
                                                                    u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
@@ -1113,6 +1201,9 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
 
     BCE_PROF_INIT();
     const u32 nsteps = AP ? n * P.dR : n;
+    // FOLD: word offset (from `acc`) of the evaluation-form accumulator the step reads; the step writes the other one
+    // (offset 2 NP = digit rows 0, 1).
+    u32 cb = 0;
     if constexpr (WPS >= 4) __builtin_amdgcn_s_setprio(2);
     for (u32 step = 0; step < nsteps; ++step) {
         u32 ap = 0, rowb;
@@ -1150,7 +1241,7 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
 #pragma unroll
             for (int r = 0; r < 4; ++r) u[r] = x[r] + ((x[r] < Qh) ? off : offm);
 #pragma unroll
-            for (u32 l = 0; l < (u32)DG; ++l) {
+            for (u32 l = FOLD ? 1 : 0; l < (u32)DG; ++l) {
                 u32 v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_ubfe(u[r], l * gb, gb) + bias;
@@ -1171,7 +1262,13 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
         // waves fill the gaps (+1..4 %, same-box A/B; the opposite policy costs 7 %, and a lone workgroup loses 6 %
         // with either, hence only in this build)
         if constexpr (WPS >= 4) __builtin_amdgcn_s_setprio(0);
-        ntt_forward_wave_low8(dct + wave * NP, twf, lane, Q);
+        if constexpr (FOLD) {
+            // six rows (2..7) on eight waves: whole rows 2..5 on waves 0..3, rows 6 and 7 as halves on waves 4..7
+            if (wave < 4) ntt_forward_wave_low8(dct + (2 + wave) * NP, twf, lane, Q);
+            else ntt_forward_half_low8(dct + (6 + ((wave - 4) >> 1)) * NP, (wave - 4) & 1u, twf, lane, Q);
+        } else {
+            ntt_forward_wave_low8(dct + wave * NP, twf, lane, Q);
+        }
         if constexpr (WPS >= 4) __builtin_amdgcn_s_setprio(2);
         BCE_PROF_MARK(2);
         if constexpr (PR < R) {
@@ -1189,24 +1286,28 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
             u64 sp[4] = {0, 0, 0, 0}, sn[4] = {0, 0, 0, 0};
 #pragma unroll
             for (u32 l = 0; l < R; ++l) {
-                const uint4 d = *reinterpret_cast<const uint4*>(dct + l * NP + mpp);
+                // FOLD: rows 0, 1 are the accumulator components themselves (< 2Q)
+                const uint4 d = *reinterpret_cast<const uint4*>((FOLD && l < 2 ? acc + cb : dct) + l * NP + mpp);
                 sp[0] += (u64)d.x * kA[l].x; sp[1] += (u64)d.y * kA[l].y; sp[2] += (u64)d.z * kA[l].z; sp[3] += (u64)d.w * kA[l].w;
                 if constexpr (!AP) {
                     sn[0] += (u64)d.x * kB[l].x; sn[1] += (u64)d.y * kB[l].y; sn[2] += (u64)d.z * kB[l].z; sn[3] += (u64)d.w * kB[l].w;
                 }
             }
             u32 anew[4];
+            const u32* const accr = acc + cb + mc * NP + mpp;
+            u32* const accw = acc + (FOLD ? 2 * NP - cb : 0) + mc * NP + mpp;
             if constexpr (AP) {
                 // acc[c] = sum_l dct[l] * ek[l][c]   (rgsw-acc-dm.cpp AddToAcc: the product REPLACES acc)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) anew[e] = barrett_fold(sp[e], P.c32, Q, P.red_shift, P.red_mu);
-                *reinterpret_cast<uint4*>(acc + mc * NP + mpp) = make_uint4(anew[0], anew[1], anew[2], anew[3]);
+                *reinterpret_cast<uint4*>(accw) = make_uint4(anew[0], anew[1], anew[2], anew[3]);
             } else {
                 const u32 a4 = ap & 3u;
                 const uint2 Ia = make_uint2(P.I4[a4], P.I4s[a4]);
                 const uint2 Ina = make_uint2(P.I4[(4u - a4) & 3u], P.I4s[(4u - a4) & 3u]);
-                ginx_mac_tail<LOGN, true>(P, psi_rsrc, Q, ap, Ia, Ina, mp0, acc + mc * NP + mpp, sp, sn, anew);
+                ginx_mac_tail<LOGN, true>(P, psi_rsrc, Q, ap, Ia, Ina, mp0, accr, accw, sp, sn, anew);
             }
+            if constexpr (FOLD) cb = 2 * NP - cb;
             split_pass0(S, twf, anew, xa, Q, P.mu32);  // mc == c, mp0 == 4 t: this thread's pass-0 registers
         }
         BCE_PROF_MARK(4);
@@ -1288,6 +1389,7 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n
     const int occ = P.occupancy_target;
     const bool ap = P.method_ap != 0;
     BrKernel kern = nullptr;
+    if (P.fold && !(P.variant != 1 && P.logN == 10 && P.dG == 4 && P.lazy)) return hipErrorInvalidValue;  // folded key, no kernel for it
     if (P.variant != 1 && P.logN == 10 && P.dG == 4 && P.lazy) {
         // N = 1024, dG = 4 (STD128 class): the split-transform kernel, with the 256-register budget while the
         // launch leaves every workgroup a CU of its own, else with the 128-register one (two per CU);
@@ -1300,7 +1402,10 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n
         // CUs to themselves keeps the separate tail kernels, which spread one bootstrap's row gather over many CUs
         const bool fuse = !x1 && tail_fused && P.fuse_tail && fused_tail_fits(P);
         LatKernel lk;
-        if (ap) lk = x1 ? k_blind_rotate_lat<4, 2, true, false> : (fuse ? k_blind_rotate_lat<4, 4, true, true> : k_blind_rotate_lat<4, 4, true, false>);
+        if (P.fold) {   // key rows l >= 1 hold ek_l - B^l ek_0 (see the kernel's FOLD note)
+            if (ap) lk = x1 ? k_blind_rotate_lat<4, 2, true, false, true> : (fuse ? k_blind_rotate_lat<4, 4, true, true, true> : k_blind_rotate_lat<4, 4, true, false, true>);
+            else lk = x1 ? k_blind_rotate_lat<4, 2, false, false, true> : (fuse ? k_blind_rotate_lat<4, 4, false, true, true> : k_blind_rotate_lat<4, 4, false, false, true>);
+        } else if (ap) lk = x1 ? k_blind_rotate_lat<4, 2, true, false> : (fuse ? k_blind_rotate_lat<4, 4, true, true> : k_blind_rotate_lat<4, 4, true, false>);
         else lk = x1 ? k_blind_rotate_lat<4, 2, false, false> : (fuse ? k_blind_rotate_lat<4, 4, false, true> : k_blind_rotate_lat<4, 4, false, false>);
         if (kernel_id) *kernel_id = x1 ? BCE_BR_SPLIT_X1 : BCE_BR_SPLIT_X2;
         if (tail_fused) *tail_fused = fuse;
@@ -1607,6 +1712,37 @@ hipError_t launch_pointwise_mac(const DevParams& P, u32* b, const u32* a, const 
                                 hipStream_t s) {
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(k_pointwise_mac, dim3(2048), dim3(256), 0, s, P, b, a, z, count, b_step);
+    return hipGetLastError();
+}
+
+// Key layout of the FOLD kernels (one-off, after key generation / import; undone on export).  One thread per
+// (RGSW ciphertext, component c, column, position): row(2l + c) -+= B^l row(c) mod Q, l = 1..dG-1.  Plain 64-bit
+// remainders: this runs once per key.
+template <typename W>
+__global__ __launch_bounds__(256) void k_fold_gadget(DevParams P, W* __restrict__ bsk, u64 rgsw, int dir) {
+    const u64 Q = P.is64 ? P.Q64 : (u64)P.Q;
+    const u64 per = 4ull * P.N, total = rgsw * per;   // (c, col, k) per RGSW ciphertext
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u64 g = i / per, rem = i - g * per;
+        const u32 c = (u32)(rem / (2ull * P.N));
+        const u64 ck = rem - (u64)c * 2 * P.N;        // col * N + k
+        W* base = bsk + g * (2ull * P.dG) * 2 * P.N;
+        const u64 e0 = (u64)base[(u64)c * 2 * P.N + ck];
+        u64 bl = 1;
+        for (u32 l = 1; l < P.dG; ++l) {
+            bl = (bl << P.gBits) % Q;
+            const u64 t = (u64)(((unsigned __int128)bl * e0) % Q);
+            W* w = base + (u64)(2 * l + c) * 2 * P.N + ck;
+            const u64 v = (u64)*w;
+            *w = (W)(dir > 0 ? (v >= t ? v - t : v + Q - t) : (v + t >= Q ? v + t - Q : v + t));
+        }
+    }
+}
+
+hipError_t launch_fold_gadget(const DevParams& P, void* bsk, u64 rgsw, int dir, hipStream_t s) {
+    if (rgsw == 0) return hipSuccess;
+    if (P.is64) hipLaunchKernelGGL(k_fold_gadget<u64>, dim3(4096), dim3(256), 0, s, P, static_cast<u64*>(bsk), rgsw, dir);
+    else hipLaunchKernelGGL(k_fold_gadget<u32>, dim3(4096), dim3(256), 0, s, P, static_cast<u32*>(bsk), rgsw, dir);
     return hipGetLastError();
 }
 

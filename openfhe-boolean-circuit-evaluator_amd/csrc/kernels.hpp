@@ -38,6 +38,8 @@ struct DevParams {
                            // transform kernel forced to its 256- / 128-register build (development knob BCE_VARIANT)
     u32 cu_count;          // compute units of the device (automatic choice: a launch of <= cu_count workgroups)
     u32 fuse_tail;         // 1: saturated launches of the split-transform kernel run the tail in their epilogue (BCE_FUSE_TAIL=0 disables)
+    u32 fold;              // 1: the key is stored with the lowest gadget digit folded in (rows l >= 1 hold ek_l - B^l ek_0) and
+                           // the kernels multiply the digit-0 rows by the evaluation-form accumulator itself (BCE_FOLD=0 disables)
     u32 I4[4], I4s[4];     // powers of I = psi^(N/2) (primitive 4th root of unity) and Shoup companions
     const uint2* tw_f;  // [N] (psi^brv(i), shoup), index m+i as in the CT forward NTT; the inverse
                         // transform derives psi^-k = -psi^(N-k) from the same table
@@ -102,6 +104,10 @@ hipError_t launch_pool_pack(const DevParams& P, const bce_gate_desc* d_descs, u3
 
 // in-place negacyclic NTT of `count` polys, u32 [count][N] in global memory
 hipError_t launch_ntt_batch(const DevParams& P, u32* polys, u32 count, int inverse, hipStream_t s);
+
+// In place on `rgsw` RGSW ciphertexts [R = 2 dG rows][2][N] (evaluation form, integer words: u32, or u64 when P.is64):
+// dir = +1: row(2l + c) -= B^l row(c) for l = 1..dG-1 (the layout the FOLD kernels read); dir = -1 undoes it.
+hipError_t launch_fold_gadget(const DevParams& P, void* bsk, u64 rgsw, int dir, hipStream_t s);
 
 // b[p*b_step][k] += a[p][k] * z[k] mod Q for count polys (key generation)
 hipError_t launch_pointwise_mac(const DevParams& P, u32* b, const u32* a, const u32* z, u32 count, u32 b_step,
