@@ -245,21 +245,6 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         P.cu_count = (u32)cus;
         const char* ft = std::getenv("BCE_FUSE_TAIL");  // development / parity knob: 0 keeps the separate tail kernels
         P.fuse_tail = (ft && ft[0] == '0') ? 0 : 1;
-        // Lowest gadget digit folded into the key (kernels.hip, FOLD): needs a kernel that has the variant and an EXACT
-        // SignedDigitDecompose -- every centred residue d in [-(Q - Q/2), Q/2) must equal sum_l r_l B^l with dG digits
-        // r_l in [-B/2, B/2) (then the carry the reference drops after the last digit is always zero).  TOY (27-bit Q,
-        // B = 2^9, 3 digits) fails it for the top 0.1 % of residues; STD128* (B = 2^7, 4 digits) and STD192* (37-bit Q,
-        // B = 2^13, 3 digits) pass.  BCE_FOLD=0 keeps the plain key (development / parity knob).
-        {
-            const u128 Bg = (u128)1 << c->gBits;
-            u128 span = 0, pw = 1;
-            for (u32 l = 0; l < c->dG; ++l) { span += pw; pw *= Bg; }
-            const u128 hi = (Bg / 2 - 1) * span, lo = (Bg / 2) * span;       // largest / smallest (negated) representable value
-            const bool exact = (u128)(Q >> 1) <= hi + 1 && (u128)(Q - (Q >> 1)) <= lo;
-            const bool has_kernel = !c->is64 && c->logN == 10 && c->dG == 4 && P.lazy && P.variant != 1;
-            const char* fo = std::getenv("BCE_FOLD");
-            P.fold = (exact && has_kernel && !(fo && fo[0] == '0')) ? 1 : 0;
-        }
     }
     {
         u64 I = pow_mod(c->psi, N / 2, Q), v = 1;
@@ -307,6 +292,22 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         if (hipMalloc(&c->d_tw64d, sizeof(double2) * N) != hipSuccess) { g_create_error = "hipMalloc(twiddles64d) failed"; return BCE_ERR_HIP; }
         hipMemcpy(c->d_tw64d, twd.data(), sizeof(double2) * N, hipMemcpyHostToDevice);
         P.tw64d = c->d_tw64d;
+    }
+    // Lowest gadget digit folded into the key (kernels.hip, FOLD): needs a kernel that has the variant and an EXACT
+    // SignedDigitDecompose -- every centred residue d in [-(Q - Q/2), Q/2) must equal sum_l r_l B^l with dG digits
+    // r_l in [-B/2, B/2) (then the carry the reference drops after the last digit is always zero).  TOY (27-bit Q,
+    // B = 2^9, 3 digits) fails it for the top 0.1 % of residues; STD128* (B = 2^7, 4 digits) and STD192* (37-bit Q,
+    // B = 2^13, 3 digits) pass.  BCE_FOLD=0 keeps the plain key (development / parity knob).
+    {
+        const u128 Bg = (u128)1 << c->gBits;
+        u128 span = 0, pw = 1;
+        for (u32 l = 0; l < c->dG; ++l) { span += pw; pw *= Bg; }
+        const u128 hi = (Bg / 2 - 1) * span, lo = (Bg / 2) * span;       // largest / smallest (negated) representable value
+        const bool exact = (u128)(Q >> 1) <= hi + 1 && (u128)(Q - (Q >> 1)) <= lo;
+        const bool has_kernel = c->is64 ? (P.fp64 && c->logN == 11 && c->dG == 3)                      // kernels64.hip, N = 2048
+                                         : (c->logN == 10 && c->dG == 4 && P.lazy && P.variant != 1);  // kernels.hip, split transform
+        const char* fo = std::getenv("BCE_FOLD");
+        P.fold = (exact && has_kernel && !(fo && fo[0] == '0')) ? 1 : 0;
     }
     P.pool_stride = n + 1;
     c->enc_seed_ok = os_entropy(c->enc_seed);

@@ -899,7 +899,13 @@ __device__ __forceinline__ void split_inverse11(const double* src, double* bufA,
 #define BCE_W16_NBUF_GINX 1
 #define BCE_W16_NPRE_GINX 0
 #endif
-template <int LOGN, int DG, bool AP, bool SPLIT = false, bool W16 = false,
+// FOLD (with SPLIT): the lowest gadget digit is never transformed -- the key arrives with rows l >= 1 replaced by
+// ek_l - B^l ek_0 and the MAC multiplies the digit-0 rows by the evaluation-form accumulator itself (see the FOLD note of
+// k_blind_rotate_lat in kernels.hip; SignedDigitDecompose is exact for these parameters, checked by the host).  Four
+// forward transforms per step instead of six = eight half-transforms, one per wave (two per SIMD; 16-wave build: waves
+// 0..7).  The accumulator is double-buffered between `acc` and digit rows 0, 1; the inverse transform's exchange buffers
+// move to digit rows 2..5.
+template <int LOGN, int DG, bool AP, bool SPLIT = false, bool W16 = false, bool FOLD = false,
           u32 NBUF_ = (W16 ? (AP ? BCE_W16_NBUF_AP : BCE_W16_NBUF_GINX) : (AP ? 3 : 2)),
           u32 NPRE_ = (W16 ? (AP ? BCE_W16_NPRE_AP : BCE_W16_NPRE_GINX) : (AP ? 2 : 1))>
 __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind_rotate64d(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
@@ -909,6 +915,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
     constexpr u32 R = 2 * DG, T = W16 ? 1024 : (SPLIT ? 512 : 64 * R);
     static_assert(!SPLIT || (LOGN == 11 && R <= 8 && R >= 4), "split inverse transform: N = 2048");
     static_assert(!W16 || (SPLIT && R == 6), "16-wave variant: N = 2048, three gadget digits");
+    static_assert(!FOLD || (SPLIT && R == 6), "folded gadget digit: N = 2048, three gadget digits");
     extern __shared__ __align__(16) double smemd[];
     double* acc = smemd;          // [2][NP] evaluation form, |value| <= 0.6 Q
     double* dct = acc + 2 * NP;   // [R][NP]
@@ -977,6 +984,11 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
         for (u32 l = 0; l < (u32)DG; ++l) { doff += pw; pw *= Bd; }
     }
     const u32 nsteps = AP ? n * P.dR : n;
+    // FOLD: the step reads the evaluation-form accumulator at `cur` (also as MAC rows 0, 1) and writes the new one to `nxt`
+    double* cur = acc;
+    double* nxt = FOLD ? dct : acc;
+    // exchange buffers of the split inverse transform: digit rows that are dead until the digits are written
+    constexpr int XA = FOLD ? 2 : 0, XB = FOLD ? 4 : 2;
     BCE_PROF_INIT();
     for (u32 step = 0; step < nsteps; ++step) {
         u32 ap = 0;
@@ -1027,7 +1039,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
             const u32 c = wave >> 2, t = tid_v & 255u;
             double x[8];
             // exchange buffers live in dct rows 0..3 (dead until the digits are written)
-            split_inverse11(acc + c * NP, dct + c * NP, dct + (2 + c) * NP, twa, t, Q, x);
+            split_inverse11(cur + c * NP, dct + (XA + c) * NP, dct + (XB + c) * NP, twa, t, Q, x);
             block_sync_lds();  // every thread has read its pass-3 inputs: the digit rows may be overwritten
             // digits, then the first three FORWARD stages (bits 10, 9, 8 = this thread's register index) on each digit
             // in registers: the forward transform below is left with bits 7..0 (two passes)
@@ -1049,6 +1061,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
                     v[r] = fma(-fl, Bd, u[r]) - halfB;  // digit in [-B/2, B/2)
                     u[r] = fl;
                 }
+                if (FOLD && l == 0) continue;   // digit 0 only advances the running quotient
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {  // bit 10: (r, r+4), twiddle tw[1]
                     const double T = modmul_q(v[r + 4], w10.x, w10.y, Q);
@@ -1091,7 +1104,11 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
         BCE_PROF_MARK(0);
         block_sync_lds();
         BCE_PROF_MARK(1);
-        if constexpr (W16) {
+        if constexpr (FOLD) {
+            // rows 2..5 as eight half-transforms: waves w and w + 4 share a row (and a SIMD)
+            if (wave < 8) forward_half<LOGN>(dct + (2 + (wave & 3u)) * NP, twa, (wave >> 2) * 64u + lane_v, Q);
+            else block_sync_lds();
+        } else if constexpr (W16) {
             forward_phase_halves<LOGN>(dct, NP, twa, wave, lane_v, Q);
         } else if constexpr (SPLIT) {
             forward_phase_balanced<LOGN>(dct, NP, twa, wave, lane_v, Q);
@@ -1115,7 +1132,8 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
                 double sp[2] = {0.0, 0.0}, sn[2] = {0.0, 0.0};
 #pragma unroll
                 for (u32 l = 0; l < R; ++l) {
-                    const double2 d = *reinterpret_cast<const double2*>(dct + l * NP + pp);
+                    // FOLD: rows 0, 1 are the accumulator components themselves
+                    const double2 d = *reinterpret_cast<const double2*>((FOLD && l < 2 ? cur : dct) + l * NP + pp);
                     const double2 kp = kb[k % NBUF][l];
                     sp[0] += modmul(d.x, kp.x, invQ, Q);
                     sp[1] += modmul(d.y, kp.y, invQ, Q);
@@ -1143,7 +1161,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
                     mn[0] = psi_pow<LOGN>(tw, (2 * N - ex) & (2 * N - 1), Q);
                     mp[1] = odd ? Q - mp[0] : mp[0];
                     mn[1] = odd ? Q - mn[0] : mn[0];
-                    const double2 old = *reinterpret_cast<const double2*>(acc + c * NP + pp);
+                    const double2 old = *reinterpret_cast<const double2*>(cur + c * NP + pp);
                     const double oldv[2] = {old.x, old.y};
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
@@ -1152,13 +1170,14 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
                         a[e] = modred(t, invQ, Q);
                     }
                 }
-                *reinterpret_cast<double2*>(acc + c * NP + pp) = make_double2(a[0], a[1]);
+                *reinterpret_cast<double2*>(nxt + c * NP + pp) = make_double2(a[0], a[1]);
             }
         };
         for_each_index(mac_item, std::make_integer_sequence<u32, ITEMS>{});
         BCE_PROF_MARK(4);
         block_sync_lds();
         BCE_PROF_MARK(5);
+        if constexpr (FOLD) { double* const t = cur; cur = nxt; nxt = t; }
     }
     BCE_PROF_FLUSH();
     if (W16 && tid >= 512u) {
@@ -1167,7 +1186,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
     } else if constexpr (SPLIT) {
         const u32 c = wave >> 2, t = tid & 255u;
         double x[8];
-        split_inverse11(acc + c * NP, dct + c * NP, dct + (2 + c) * NP, twa, t, Q, x);
+        split_inverse11(cur + c * NP, dct + (XA + c) * NP, dct + (XB + c) * NP, twa, t, Q, x);
         u64* out = acc_out + ((size_t)blockIdx.x * 2 + c) * N;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -1233,10 +1252,12 @@ hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32
                 // items do not fit the 128-register budget (16 waves: +9 %).  BCE_VARIANT=2 / 3 force 8 / 16 waves.
                 const bool w16 = P.variant == 3 || (P.variant != 2 && ap);
                 if (w16) {
-                    kern = ap ? wd::k_blind_rotate64d<11, 3, true, true, true> : wd::k_blind_rotate64d<11, 3, false, true, true>;
+                    if (P.fold) kern = ap ? wd::k_blind_rotate64d<11, 3, true, true, true, true> : wd::k_blind_rotate64d<11, 3, false, true, true, true>;
+                    else kern = ap ? wd::k_blind_rotate64d<11, 3, true, true, true> : wd::k_blind_rotate64d<11, 3, false, true, true>;
                     threads = 1024;
                 } else {
-                    kern = ap ? wd::k_blind_rotate64d<11, 3, true, true> : wd::k_blind_rotate64d<11, 3, false, true>;
+                    if (P.fold) kern = ap ? wd::k_blind_rotate64d<11, 3, true, true, false, true> : wd::k_blind_rotate64d<11, 3, false, true, false, true>;
+                    else kern = ap ? wd::k_blind_rotate64d<11, 3, true, true> : wd::k_blind_rotate64d<11, 3, false, true>;
                     threads = 512;
                 }
                 break;
@@ -1255,7 +1276,7 @@ hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32
     } else if (P.dG == 4 && P.logN == 9) {
         kern = ap ? w64::k_blind_rotate64<9, 4, true> : w64::k_blind_rotate64<9, 4, false>;
     }
-    if (!kern) return hipErrorInvalidValue;
+    if (!kern || (P.fold && !(P.fp64 && P.dG == 3 && P.logN == 11))) return hipErrorInvalidValue;  // folded key: N = 2048 fp64 kernels only
     const size_t lds = blind_rotate64_lds_bytes(P);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
