@@ -386,6 +386,7 @@ def main():
                 "schedule": "bootstrap-depth levels (NOTs folded, identical ciphertexts)" if R["relevel"] else "gate levels (reference Clock rounds)",
                 "xor": "XOR_FAST (opt-in, 1 bootstrap)" if args.xor_fast else "NOT,NOT,AND,AND,OR (reference, 3 bootstraps)",
                 "bootstraps_per_step": int(total_boot / args.steps),
+                "forward_transforms_per_blind_rotation_step": cc.forward_transforms_per_step(),
                 "gates_per_s": (info["n_gates"] - info["n_output_bits"]) * args.instances * world * args.steps / elapsed,
                 "single_block_latency_s": None if block_latency_s is None else round(block_latency_s, 4),
                 "outputs_verified": bool(verified), "setup_s": round(setup_s, 2), "keygen_s": round(keygen_s, 3),

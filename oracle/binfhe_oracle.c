@@ -605,6 +605,9 @@ static void signed_digit_decompose(const bo_ctx* c, const u64* ct /*[2][N]*/, u6
         }
 }
 
+/* test hook: SignedDigitDecompose of one RLWE pair, ct [2][N] coefficient form -> dct [2 dG][N] (digits mod Q) */
+void bo_signed_digit_decompose(const bo_ctx* c, const uint64_t* ct, uint64_t* dct) { signed_digit_decompose(c, ct, dct); }
+
 typedef struct {
     u64 *ct, *dct;
 } scratch_t;

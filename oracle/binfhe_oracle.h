@@ -104,6 +104,9 @@ void bo_keyswitch(const bo_ctx*, const uint64_t* lweN, uint64_t* out);
 void bo_modswitch_final(const bo_ctx*, const uint64_t* in, uint64_t* out);
 
 /* negacyclic NTT helpers in the oracle's own (OpenFHE) ordering; in place, length N */
+/* SignedDigitDecompose (rgsw-acc.cpp) of one RLWE pair: ct [2][N] coefficient form -> dct [2 dG][N], digit l of
+ * component j at row 2l + j, negative digits as r + Q */
+void bo_signed_digit_decompose(const bo_ctx*, const uint64_t* ct, uint64_t* dct);
 void bo_ntt_forward(const bo_ctx*, uint64_t* x);
 void bo_ntt_inverse(const bo_ctx*, uint64_t* x);
 

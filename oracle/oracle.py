@@ -81,6 +81,7 @@ def lib():
         L.bo_modswitch_final.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.bo_ntt_forward.argtypes = [C.c_void_p, C.c_void_p]
         L.bo_ntt_inverse.argtypes = [C.c_void_p, C.c_void_p]
+        L.bo_signed_digit_decompose.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.bo_eval_gates.restype = C.c_uint64
         L.bo_eval_gates.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
         _lib = L
@@ -219,6 +220,13 @@ class Oracle:
         x = np.array(x, dtype=np.uint64)
         lib().bo_ntt_inverse(self.h, _p(x))
         return x
+
+    def signed_digit_decompose(self, ct):
+        """ct: [2][N] coefficient form -> [2 dG][N] digits mod Q (row 2l + j = digit l of component j)."""
+        ct = np.ascontiguousarray(ct, dtype=np.uint64).reshape(2, self.N)
+        out = np.zeros((2 * self.params["dG"], self.N), dtype=np.uint64)
+        lib().bo_signed_digit_decompose(self.h, _p(ct), _p(out))
+        return out
 
     # -- batched ----------------------------------------------------------
     def eval_gates(self, pool, descs, nthreads=0):

@@ -416,6 +416,20 @@ def test_q64_custom_context_bit_exact_stages(bce, orc, method, arith, dg, N, mon
         assert np.array_equal(acc2, acc) and np.array_equal(lweN2, lweN) and np.array_equal(ks2, ks)
         assert np.array_equal(c2.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32)), out)
         c2.close()
+        # both builds keep the key with the lowest gadget digit folded in (4 forward transforms per step); the plain-key
+        # instantiations (6 transforms; what an inexact gadget would fall back to) must give the same words
+        assert c.forward_transforms_per_step() == 4
+        monkeypatch.setenv("BCE_FOLD", "0")
+        for var in ("2", "3"):
+            monkeypatch.setenv("BCE_VARIANT", var)
+            c3 = bce.BinFHEContext(method=getattr(bce, method), custom=params)
+            assert c3.forward_transforms_per_step() == 6
+            c3.import_keys(o.sk(), o.z(), o.bsk(), o.ksk())
+            c3.pool_reserve(3 * nb)
+            c3.lwe_write(np.arange(2 * nb, dtype=np.uint32), np.concatenate([np.stack([ca, cb]) for (_, _, _, ca, cb) in cases]))
+            acc3, lweN3, ks3 = c3.debug_eval_stages(descs)
+            assert np.array_equal(acc3, acc) and np.array_equal(lweN3, lweN) and np.array_equal(ks3, ks)
+            c3.close()
     for i, (g, a, b, ca, cb) in enumerate(cases):
         r_acc = o.blind_rotate(g, o.gate_prep(g, ca, cb))
         assert np.array_equal(acc[i], r_acc), "64-bit accumulator differs, case %d" % i
@@ -550,3 +564,40 @@ def test_std128_fused_tail_every_stage_equals_separate_tail_and_oracle(std128, b
         r_ks = o.keyswitch(r_lweN)
         assert np.array_equal(acc_s[k], r_acc) and np.array_equal(lweN_s[k], r_lweN) and np.array_equal(ks_s[k], r_ks)
         assert np.array_equal(out_s[k], o.modswitch_final(r_ks)) and o.decrypt(out_s[k]) == _truth(g, a, b)
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+def test_std128_plain_key_split_kernels_and_folded_key_round_trip(std128, bce, variant, monkeypatch):
+    """STD128_OPT contexts keep the bootstrapping key with the lowest gadget digit folded in (rows l >= 1 hold
+    ek_l - B^l ek_0; 6 forward transforms per step instead of 8).  BCE_FOLD=0 keeps the plain key and the 8-transform
+    instantiations of both split-transform builds: same accumulator, same ciphertext, both equal to the oracle's;
+    and a folded context exports the canonical key it imported."""
+    o, c_fold = std128
+    assert c_fold.forward_transforms_per_step() == 6
+    monkeypatch.setenv("BCE_FOLD", "0")
+    monkeypatch.setenv("BCE_VARIANT", str(variant))
+    c = bce.BinFHEContext(bce.STD128_OPT, bce.GINX)
+    assert c.forward_transforms_per_step() == 8
+    c.import_keys(o.sk(), o.z(), o.bsk(), o.ksk())
+    cases = [x for x in _gate_cases(o, base=7000 + 100 * variant) if x[0] in (bce.OR, bce.NAND, bce.XNOR_FAST)][2:6]
+    nb = len(cases)
+    for ctx in (c, c_fold):
+        ctx.pool_reserve(3 * nb)
+        ctx.lwe_write(np.arange(2 * nb, dtype=np.uint32), np.concatenate([np.stack([ca, cb]) for (_, _, _, ca, cb) in cases]))
+    descs = [(g, 2 * i, 2 * i + 1, 2 * nb + i) for i, (g, _, _, _, _) in enumerate(cases)]
+    acc, lweN, ks = c.debug_eval_stages(descs)
+    acc_f, lweN_f, ks_f = c_fold.debug_eval_stages(descs)
+    assert np.array_equal(acc, acc_f) and np.array_equal(lweN, lweN_f) and np.array_equal(ks, ks_f)
+    out = c.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32))
+    assert np.array_equal(out, c_fold.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32)))
+    for i, (g, a, b, ca, cb) in enumerate(cases):
+        assert np.array_equal(acc[i], o.blind_rotate(g, o.gate_prep(g, ca, cb))), "accumulator differs, case %d" % i
+        assert np.array_equal(out[i], o.eval_bingate(g, ca, cb))
+    if variant == 2:
+        assert np.array_equal(c_fold.export_bsk(), o.bsk())   # un-folded on the way out
+    c.close()
+
+
+def test_toy_keeps_the_plain_key(toy):
+    """TOY's gadget (27-bit Q, 3 digits base 2^9) is not exact (tests/test_oracle.py): no folding there."""
+    assert toy[1].forward_transforms_per_step() == 6 == 2 * toy[0].params["dG"]

@@ -154,3 +154,40 @@ def test_std128_single_gate(orc):
     ca, cb = o.encrypt(1, 0), o.encrypt(0, 1)
     r = o.eval_bingate(orc.OR, ca, cb)
     assert o.decrypt(r) == 1 and abs(o.noise(r, 1)) < 128
+
+
+@pytest.mark.parametrize("ps,exact", [("STD128_OPT", True), ("STD128", True), ("STD192", True), ("TOY", False)])
+def test_signed_digit_decompose_is_exact_where_the_engine_folds_the_lowest_digit(orc, ps, exact):
+    """The HIP kernels of the STD128* and STD192 sets never transform the lowest gadget digit: they use
+    sum_l B^l dct_l = acc (mod Q) and read NTT(dct_0) off the evaluation-form accumulator.  That identity
+    holds iff SignedDigitDecompose (rgsw-acc.cpp) is EXACT, i.e. the carry it drops after the last digit is zero for
+    every centred residue.  Pinned here on the oracle's decomposition: exact for 27-bit Q with 4 digits base 2^7 and
+    for 37-bit Q with 3 digits base 2^13; NOT exact for TOY (27-bit Q, 3 digits base 2^9: the top 0.1 % of the
+    positive residues lose a carry), which is why the engine keeps the plain key there.  The closed-form predicate
+    below is the one engine.cpp evaluates at context creation."""
+    o = orc.Oracle(getattr(orc, ps), orc.GINX)
+    Q, B, dG, N = o.params["Q"], o.params["baseG"], o.params["dG"], o.N
+    span = sum(B ** l for l in range(dG))
+    hi, lo = (B // 2 - 1) * span, (B // 2) * span      # largest / smallest (negated) value dG signed digits reach
+    assert ((Q >> 1) <= hi + 1 and Q - (Q >> 1) <= lo) == exact
+    rng = np.random.default_rng(11)
+    edge = [0, 1, 2, Q - 1, Q - 2, (Q >> 1) - 1, Q >> 1, (Q >> 1) + 1, (Q >> 1) - 2, hi % Q, (hi + 1) % Q, (Q - lo) % Q]
+    edge += [(B ** l * k) % Q for l in range(1, dG) for k in (1, B // 2 - 1, B // 2, B // 2 + 1, B - 1)]
+    edge += [(Q - B ** l * k) % Q for l in range(1, dG) for k in (1, B // 2, B // 2 + 1)]
+    top = (Q >> 1) - 1 - rng.integers(0, 1 << 12, size=256)                 # the residues just below Q/2
+    vals = np.concatenate([np.array(edge, dtype=np.uint64), top.astype(np.uint64),
+                           rng.integers(0, Q, size=2 * N - len(edge) - 256, dtype=np.uint64)])
+    ct = vals.reshape(2, N)
+    dct = o.signed_digit_decompose(ct)
+    rec = np.zeros((2, N), dtype=object)
+    for l in range(dG):
+        for j in range(2):
+            rec[j] = (rec[j] + dct[2 * l + j].astype(object) * (B ** l)) % Q
+    bad = rec != ct.astype(object)
+    if exact:
+        assert not bad.any()
+    else:
+        assert bad.any()
+        # only residues above the largest representable value lose their carry
+        assert all(int(v) > hi and int(v) < (Q >> 1) for v in ct[bad])
+    o.close()

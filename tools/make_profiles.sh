@@ -33,7 +33,7 @@ PY
 cd /tmp
 /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -S --cuda-device-only -o /tmp/bce_kernels.s \
     "$R/openfhe-boolean-circuit-evaluator_amd/csrc/kernels.hip" 2>/dev/null
-python3 "$R/tools/valu_model.py" /tmp/bce_kernels.s k_blind_rotate_latILi4ELi4ELb0ELb1E "$P/${PRE}_valu_issue.jsonl" "$P/${PRE}_pmc_sq_lds.json" \
+python3 "$R/tools/valu_model.py" /tmp/bce_kernels.s k_blind_rotate_latILi4ELi4ELb0ELb1ELb1E "$P/${PRE}_valu_issue.jsonl" "$P/${PRE}_pmc_sq_lds.json" \
     "k_blind_rotate_lat<4,4> (split transform, 2 workgroups/CU)" 4 > "$P/${PRE}_valu_model.json"
 python3 - "$P/${PRE}_valu_model.json" <<'PY'
 import json, sys
