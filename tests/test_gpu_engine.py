@@ -114,9 +114,9 @@ def test_std128_gates_bit_exact(std128, bce):
 
 @pytest.mark.parametrize("variant", [1, 2, 3])
 def test_std128_every_blind_rotation_kernel_bit_exact(std128, bce, variant, monkeypatch):
-    """N = 1024 / dG = 4 has three blind-rotation kernels (one wave per inverse transform; split transform at
-    one / two workgroups per CU) chosen by launch size; BCE_VARIANT pins one at context creation.  Each must
-    reproduce the oracle's accumulator and final ciphertext bit for bit."""
+    """N = 1024 / dG = 4 has three blind-rotation kernels (1: one wave per inverse transform, plain key; split
+    transform with the folded key at 2: one / 3: two workgroups per CU) chosen by launch size; BCE_VARIANT pins one at
+    context creation.  Each must reproduce the oracle's accumulator and final ciphertext bit for bit."""
     o, c_auto = std128
     monkeypatch.setenv("BCE_VARIANT", str(variant))
     c = bce.BinFHEContext(bce.STD128_OPT, bce.GINX)
