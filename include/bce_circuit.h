@@ -90,6 +90,20 @@ int bce_circuit_set_xor_fast(bce_circuit*, int on);
 /* opt-in extension: schedule by bootstrap depth (NOTs folded into consumers, an XOR's OR launched with
  * the next level's ANDs).  Same ciphertexts, fewer dependent launches; encrypted-only runs, no verify. */
 int bce_circuit_set_relevel(bce_circuit*, int on);
+/* The bootstrap-depth schedule fills its steps BY SLACK up to the launch staircase of the engine (default on): one
+ * bootstrap is one workgroup, so a frontier call costs one bootstrap latency up to `lone` bootstraps and one more round
+ * per `full` beyond (bce_launch_capacity); a step holding K x count bootstraps is topped up to the next stair with the
+ * ready gates of least slack.  Same number of steps, same ciphertexts (which step a gate runs in does not change its
+ * result), fewer half-empty launches.  lone = full = 0: capacities from the engine; explicit values are for tests and
+ * engine-less (plaintext) circuits.  Call before SetInput (the XOR temporaries of a step are part of the slot stride). */
+int bce_circuit_set_balance(bce_circuit*, int on, uint32_t lone, uint32_t full);
+/* Bootstraps per step of the current bootstrap-depth schedule, for ONE instance: writes min(*n_steps, cap) entries and
+ * sets *n_steps to the number of steps. */
+int bce_circuit_relevel_steps(const bce_circuit*, uint32_t* sizes, uint32_t cap, uint32_t* n_steps);
+/* Self-check of that schedule: every step reads only registers written by earlier steps (or inputs / constants), every XOR
+ * temporary is consumed exactly one step after it is produced, every gate output is written once.  BCE_OK or
+ * BCE_ERR_STATE with the finding in bce_circuit_last_error. */
+int bce_circuit_check_relevel(bce_circuit*);
 /* K independent input sets evaluated in lock-step (call before SetInput) */
 int bce_circuit_set_instances(bce_circuit*, uint32_t k);
 /* Circuit::SetInput, src/circuit.cpp:455-530: bits = concatenation of the input buses,

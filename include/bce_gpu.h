@@ -179,6 +179,11 @@ int bce_bytes_per_bootstrap_parts(const bce_ctx*, uint64_t out[3]);
  * or 2 dG - 2 when this context keeps its key with the lowest gadget digit folded in (same accumulator words; the
  * decomposition is exact for the parameter set and the digit-0 rows multiply the accumulator itself) */
 uint32_t bce_forward_transforms_per_step(const bce_ctx*);
+/* Launch granularity of this context's blind-rotation kernels, for callers that shape their frontiers (the host
+ * scheduler of bce_circuit.h does): one bootstrap is one workgroup, so a call's time is a staircase in its size.
+ * *lone = bootstraps up to which every workgroup has a compute unit to itself (one bootstrap latency per call),
+ * *full = bootstraps resident at once when the device is saturated (each further multiple costs one more round). */
+int bce_launch_capacity(const bce_ctx*, uint32_t* lone, uint32_t* full);
 
 /* ---- in-library collective (multi-GPU, one process per GPU) ---------------------------------------------
  * RCCL all-gather issued on the engine's own stream, so that the exchange of boundary ciphertexts between two

@@ -57,7 +57,7 @@ ENGINE_SYMBOLS = [
     "bce_keygen", "bce_import_keys", "bce_import_keys_file", "bce_export_keys_file", "bce_bsk_words", "bce_ksk_words", "bce_export_sk", "bce_export_bsk",
     "bce_export_ksk", "bce_pool_reserve", "bce_pool_slots", "bce_lwe_write", "bce_lwe_read",
     "bce_encrypt_bits", "bce_set_encrypt_seed", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize",
-    "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_forward_transforms_per_step", "bce_rccl_available", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
+    "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_forward_transforms_per_step", "bce_launch_capacity", "bce_rccl_available", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
     "bce_rccl_shutdown", "bce_debug_eval_stages", "bce_debug_ntt",
 ]
 
@@ -115,6 +115,7 @@ def lib():
     L.bce_bytes_per_bootstrap_parts.argtypes = [vp, C.POINTER(u64)]
     L.bce_forward_transforms_per_step.argtypes = [vp]
     L.bce_forward_transforms_per_step.restype = C.c_uint32
+    L.bce_launch_capacity.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.bce_rccl_unique_id.argtypes = [C.c_char_p]
     L.bce_rccl_init.argtypes = [vp, C.c_char_p, i32, i32]
     L.bce_rccl_allgather.argtypes = [vp, vp, vp, u64]
@@ -309,6 +310,11 @@ class BinFHEContext:
     def forward_transforms_per_step(self):
         return int(self._L.bce_forward_transforms_per_step(self.h))
 
+    def launch_capacity(self):
+        lone, full = C.c_uint32(), C.c_uint32()
+        self._ck(self._L.bce_launch_capacity(self.h, C.byref(lone), C.byref(full)))
+        return int(lone.value), int(full.value)
+
     # --- staged outputs for parity ---
     def debug_eval_stages(self, descs):
         arr = make_descs(descs)
@@ -349,7 +355,7 @@ CIRCUIT_SYMBOLS = [
     "bce_circuit_create", "bce_circuit_destroy", "bce_circuit_last_error", "bce_circuit_read_file",
     "bce_circuit_read_bristol", "bce_circuit_get_info", "bce_circuit_reset", "bce_circuit_rearm", "bce_circuit_set_plaintext",
     "bce_circuit_set_encrypted", "bce_circuit_set_verify", "bce_circuit_get_flags", "bce_circuit_set_batched",
-    "bce_circuit_set_encrypt_mode", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
+    "bce_circuit_set_encrypt_mode", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_balance", "bce_circuit_relevel_steps", "bce_circuit_check_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
     "bce_circuit_get_output", "bce_circuit_get_buses", "bce_circuit_get_counts", "bce_circuit_get_stats", "bce_circuit_dump",
     "bce_circuit_set_exchange", "bce_circuit_enable_rccl", "bce_circuit_exchange_capacity", "bce_assemble_bristol", "bce_pool_gather",
     "bce_pool_scatter",
@@ -378,6 +384,9 @@ def _bind_circuit():
         getattr(L, "bce_circuit_" + name).argtypes = [vp, i32]
     L.bce_circuit_get_flags.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.bce_circuit_set_instances.argtypes = [vp, u32]
+    L.bce_circuit_set_balance.argtypes = [vp, i32, u32, u32]
+    L.bce_circuit_relevel_steps.argtypes = [vp, C.POINTER(u32), u32, C.POINTER(u32)]
+    L.bce_circuit_check_relevel.argtypes = [vp]
     L.bce_circuit_set_input.argtypes = [vp, u32, vp, u32, vp]
     L.bce_circuit_get_output.argtypes = [vp, u32, vp]
     L.bce_circuit_get_buses.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), u32, C.POINTER(u32), C.POINTER(u32), u32]
@@ -519,6 +528,21 @@ class Circuit:
 
     def setInstances(self, k):
         self._ck(self._L.bce_circuit_set_instances(self.h, int(k)))
+
+    def setBalance(self, on, lone=0, full=0):
+        """bootstrap-depth schedule filled by slack up to the engine's launch staircase (default on); before SetInput"""
+        self._ck(self._L.bce_circuit_set_balance(self.h, int(on), int(lone), int(full)))
+
+    def relevel_steps(self):
+        """bootstraps per step of the bootstrap-depth schedule, one instance"""
+        n = C.c_uint32(0)
+        self._ck(self._L.bce_circuit_relevel_steps(self.h, None, 0, C.byref(n)))
+        buf = (C.c_uint32 * max(1, n.value))()
+        self._ck(self._L.bce_circuit_relevel_steps(self.h, buf, n.value, C.byref(n)))
+        return [int(buf[i]) for i in range(n.value)]
+
+    def check_relevel(self):
+        self._ck(self._L.bce_circuit_check_relevel(self.h))
 
     def SetInput(self, inputs, instance=0):
         """inputs[k][bit], LSB = index 0 (the reference's Inputs type)"""

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <queue>
 #include <sstream>
 #include <stdexcept>
 
@@ -378,9 +379,9 @@ void Circuit::finalizeNetlist() {
         max_level_xor_ = std::max(max_level_xor_, L.n_xor);
         levels_.push_back(std::move(L));
     }
-    stride_ = (uint32_t)W + 2 * max_level_xor_;
-    buildRelevelPlan();  // also sizes the scratch slots the re-levelled schedule needs
-    stride_ = std::max(stride_, relevel_stride_);
+    base_stride_ = stride_ = (uint32_t)W + 2 * max_level_xor_;
+    inputs_set_ = false;
+    rebuildRelevel();  // also sizes the scratch slots the re-levelled schedule needs
     buildShardPlan();
     Reset();
 }
@@ -414,6 +415,7 @@ void Circuit::setInstances(unsigned k) {
     plain_.assign(instances_, std::vector<uint8_t>(wire_names_.size(), 0));
     circuitOut.assign(instances_, std::vector<uint8_t>(n_output_bits.empty() ? 0 : n_output_bits[0], 0));
     buildShardPlan();
+    rebuildRelevel();   // the balanced schedule depends on K
 }
 
 void Circuit::instanceRange(unsigned& lo, unsigned& hi) const {
@@ -536,6 +538,7 @@ void Circuit::setExchange(uint32_t rank, uint32_t world, int shard_mode, bce_all
     rank_ = rank; world_ = world; shard_mode_ = shard_mode; xfn_ = fn; xuser_ = user;
     host_send_ = host_send; host_recv_ = host_recv; dev_send_ = dev_send; dev_recv_ = dev_recv; xcap_ = capacity;
     buildShardPlan();
+    rebuildRelevel();   // the number of instances this rank evaluates may have changed
 }
 
 // after a level: publish wires whose consumers sit on other ranks (shard_mode 1)
@@ -614,21 +617,33 @@ void Circuit::gatherOutputs() {
 }
 
 // ---- re-levelled (bootstrap-depth) schedule: SURVEY 8(f2) -------------------------------------------
+// Units of the schedule: a single bootstrap (AND / OR / XOR_FAST; its output is ready one step later) or an XOR built as
+// the reference builds it (two ANDs in step s, their OR in step s + 1; ready two steps later).  ASAP placement gives the
+// bootstrap depth of the circuit, D steps.  With balance_ on, the same D steps are filled by SLACK instead: one
+// bootstrap is one workgroup, so a frontier call costs a staircase in its size (one bootstrap latency up to `lone`
+// bootstraps, then one round per `full` resident workgroups; bce_launch_capacity), and a step that holds K x count
+// bootstraps is topped up to the next stair with the ready units of least slack (ALAP order).  Units that must run now
+// (ALAP step reached) always do, so the depth stays D; which step a gate runs in does not change its ciphertext.
+void Circuit::launchCapacity(uint32_t& lone, uint32_t& full) const {
+    lone = cap_lone_; full = cap_full_;
+    if (lone == 0 || full == 0) {
+        lone = 256; full = 512;
+        if (cc) { uint32_t a = 0, b = 0; if (bce_launch_capacity(cc, &a, &b) == BCE_OK && a && b) { lone = a; full = b; } }
+    }
+}
+
 void Circuit::buildRelevelPlan() {
     const size_t W = wire_names_.size(), G = allGates.size();
     // resolve NOT chains: wire -> (base wire, negated)
-    std::vector<int> base(W), producer(W, -1);
+    std::vector<int> base(W);
     std::vector<uint8_t> neg(W, 0);
     for (size_t w = 0; w < W; ++w) base[w] = (int)w;
-    for (size_t gi = 0; gi < G; ++gi) if (allGates[gi].out >= 0) producer[allGates[gi].out] = (int)gi;
     // gates are in topological (file) order per level; walk levels so that bases are resolved first
     std::vector<uint32_t> depth(W, 0);
-    struct Node { uint32_t depth; bce_gate_desc d; };
-    std::vector<Node> nodes;
-    std::vector<uint32_t> xor_at_depth;  // XOR count whose ANDs sit at a depth (temp slot allocation)
-    auto bump = [&](uint32_t d) { if (xor_at_depth.size() <= d) xor_at_depth.resize(d + 1, 0); return xor_at_depth[d]++; };
-    struct PendingXor { uint32_t d, idx; GateRec g; uint32_t in0, in1, n0, n1; };
-    std::vector<PendingXor> xors;
+    struct Unit { uint32_t asap, start; uint8_t lat; bce_gate_desc d; int32_t p0, p1; };   // XOR: d holds (in0, in1, out, n0, n1)
+    std::vector<Unit> units;
+    std::vector<int32_t> prod(W, -1);   // base wire -> unit that produces it
+    units.reserve(G);
     for (const auto& L : levels_)
         for (int gi : L.gates) {
             const GateRec& g = allGates[gi];
@@ -640,34 +655,112 @@ void Circuit::buildRelevelPlan() {
                 const uint32_t b0 = (uint32_t)base[g.in[0]], b1 = (uint32_t)base[g.in[1]];
                 const uint32_t n0 = neg[g.in[0]], n1 = neg[g.in[1]];
                 const uint32_t d = 1 + std::max(depth[g.in[0]], depth[g.in[1]]);
+                Unit u{d, d, 1, {0, b0, b1, (uint32_t)g.out, n0, n1}, prod[b0], prod[b1]};
                 if (g.op != GateEnum::XOR) {
-                    nodes.push_back({d, {(uint32_t)(g.op == GateEnum::AND ? BCE_AND : BCE_OR), b0, b1, (uint32_t)g.out, n0, n1}});
-                    depth[g.out] = d;
+                    u.d.op = (uint32_t)(g.op == GateEnum::AND ? BCE_AND : BCE_OR);
                 } else if (xor_fast_) {
                     // XOR_FAST of negated inputs: NOT a XOR NOT b = a XOR b; one negation flips the result
-                    nodes.push_back({d, {(uint32_t)((n0 ^ n1) ? BCE_XNOR_FAST : BCE_XOR_FAST), b0, b1, (uint32_t)g.out, 0, 0}});
-                    depth[g.out] = d;
+                    u.d.op = (uint32_t)((n0 ^ n1) ? BCE_XNOR_FAST : BCE_XOR_FAST);
+                    u.d.neg0 = u.d.neg1 = 0;
                 } else {
-                    xors.push_back({d, bump(d), g, b0, b1, n0, n1});
-                    depth[g.out] = d + 1;
+                    u.lat = 2;
+                }
+                depth[g.out] = d + u.lat - 1;
+                prod[g.out] = (int32_t)units.size();
+                units.push_back(u);
+            }
+        }
+    const size_t U = units.size();
+    uint32_t D = 0;
+    for (const auto& u : units) D = std::max(D, u.asap + u.lat - 1);
+    unsigned ilo, ihi;
+    instanceRange(ilo, ihi);
+    const uint64_t K = std::max(1u, ihi - ilo);
+    if (balance_ && U) {
+        uint32_t lone, full;
+        launchCapacity(lone, full);
+        // successors (CSR) and ALAP start steps (units are in topological order)
+        std::vector<uint32_t> soff(U + 1, 0), succ;
+        for (const auto& u : units) { if (u.p0 >= 0) ++soff[u.p0 + 1]; if (u.p1 >= 0 && u.p1 != u.p0) ++soff[u.p1 + 1]; }
+        for (size_t i = 0; i < U; ++i) soff[i + 1] += soff[i];
+        succ.resize(soff[U]);
+        {
+            std::vector<uint32_t> fill(soff.begin(), soff.end() - 1);
+            for (size_t i = 0; i < U; ++i) {
+                const Unit& u = units[i];
+                if (u.p0 >= 0) succ[fill[u.p0]++] = (uint32_t)i;
+                if (u.p1 >= 0 && u.p1 != u.p0) succ[fill[u.p1]++] = (uint32_t)i;
+            }
+        }
+        std::vector<uint32_t> alap(U);
+        for (size_t i = U; i-- > 0;) {
+            uint32_t a = D - units[i].lat + 1;
+            for (uint32_t k = soff[i]; k < soff[i + 1]; ++k) a = std::min(a, alap[succ[k]] - units[i].lat);
+            alap[i] = a;
+        }
+        // list scheduling, least slack first
+        using Key = std::pair<uint32_t, uint32_t>;   // (ALAP step, unit)
+        std::priority_queue<Key, std::vector<Key>, std::greater<Key>> ready;
+        std::vector<std::vector<uint32_t>> later(D + 2);   // units that become ready at a step
+        std::vector<uint32_t> waiting(U), ready_at(U, 1);
+        for (size_t i = 0; i < U; ++i) {
+            const Unit& u = units[i];
+            waiting[i] = (u.p0 >= 0) + (u.p1 >= 0 && u.p1 != u.p0);
+            if (!waiting[i]) ready.push({alap[i], (uint32_t)i});
+        }
+        std::vector<uint32_t> ors_due(D + 2, 0);   // ORs of the XORs started one step earlier
+        std::vector<uint32_t> chosen;
+        for (uint32_t s = 1; s <= D; ++s) {
+            for (uint32_t i : later[s]) ready.push({alap[i], i});
+            chosen.clear();
+            uint64_t cnt = ors_due[s];
+            while (!ready.empty() && ready.top().first <= s) {   // no slack left
+                const uint32_t i = ready.top().second; ready.pop();
+                chosen.push_back(i); cnt += units[i].lat == 2 ? 2 : 1;
+            }
+            const uint64_t n = cnt * K;
+            const uint64_t cap = (n <= lone ? lone : (n + full - 1) / full * full) / K;
+            while (!ready.empty()) {
+                const uint32_t i = ready.top().second;
+                const uint64_t w = units[i].lat == 2 ? 2 : 1;
+                if (cnt + w > cap) break;
+                // an XOR started in the last step would put its OR beyond D only if its ALAP allowed it: it does not
+                ready.pop(); chosen.push_back(i); cnt += w;
+            }
+            for (uint32_t i : chosen) {
+                Unit& u = units[i];
+                u.start = s;
+                if (u.lat == 2) ++ors_due[s + 1];
+                for (uint32_t k = soff[i]; k < soff[i + 1]; ++k) {
+                    const uint32_t q = succ[k];
+                    ready_at[q] = std::max(ready_at[q], s + u.lat);
+                    if (--waiting[q] == 0) later[ready_at[q]].push_back(q);
                 }
             }
         }
-    uint32_t max_x = 0;
-    for (uint32_t c : xor_at_depth) max_x = std::max(max_x, c);
-    const uint32_t tmp0 = (uint32_t)W;
-    relevel_stride_ = tmp0 + 4 * max_x;  // two parity banks of 2 temporaries per XOR
-    for (const auto& x : xors) {
-        const uint32_t t1 = tmp0 + (x.d & 1) * 2 * max_x + 2 * x.idx, t2 = t1 + 1;
-        // (a AND !b), (!a AND b) with the inputs' own negations folded in, then OR one step later
-        nodes.push_back({x.d, {BCE_AND, x.in0, x.in1, t1, x.n0, x.n1 ^ 1u}});
-        nodes.push_back({x.d, {BCE_AND, x.in0, x.in1, t2, x.n0 ^ 1u, x.n1}});
-        nodes.push_back({x.d + 1, {BCE_OR, t1, t2, (uint32_t)x.g.out, 0, 0}});
+        if (!ready.empty()) throw std::logic_error("buildRelevelPlan: units left unscheduled");
     }
-    uint32_t D = 0;
-    for (const auto& nd : nodes) D = std::max(D, nd.depth);
+    // temporaries of the XORs: two parity banks (a step's ANDs write one bank while the previous step's ORs read the other)
+    std::vector<uint32_t> xor_at(D + 2, 0);
+    uint32_t max_x = 0;
+    for (const auto& u : units) if (u.lat == 2) max_x = std::max(max_x, ++xor_at[u.start]);
+    const uint32_t tmp0 = (uint32_t)W;
+    relevel_stride_ = tmp0 + 4 * max_x;
     relevel_plan_.assign(D, RStep{});
-    for (const auto& nd : nodes) relevel_plan_[nd.depth - 1].descs.push_back(nd.d);
+    std::fill(xor_at.begin(), xor_at.end(), 0);
+    for (const auto& u : units) {
+        if (u.lat == 1) {
+            relevel_plan_[u.start - 1].descs.push_back(u.d);
+        } else {
+            const uint32_t idx = xor_at[u.start]++;
+            const uint32_t t1 = tmp0 + (u.start & 1) * 2 * max_x + 2 * idx, t2 = t1 + 1;
+            // (a AND !b), (!a AND b) with the inputs' own negations folded in, then OR one step later
+            relevel_plan_[u.start - 1].descs.push_back({BCE_AND, u.d.in0, u.d.in1, t1, u.d.neg0, u.d.neg1 ^ 1u});
+            relevel_plan_[u.start - 1].descs.push_back({BCE_AND, u.d.in0, u.d.in1, t2, u.d.neg0 ^ 1u, u.d.neg1});
+            relevel_plan_[u.start].descs.push_back({BCE_OR, t1, t2, u.d.out, 0, 0});
+        }
+    }
+    relevel_K_ = (uint32_t)K;
     // NOT wires consumed by OUTPUT gates need a real ciphertext (decrypt must see EvalNOT's output)
     relevel_nots_.clear();
     std::vector<uint8_t> done_not(W, 0);
@@ -681,19 +774,77 @@ void Circuit::buildRelevelPlan() {
         }
 }
 
+// (re)build the bootstrap-depth schedule for the current K / capacities and size the per-instance slot stride for it.
+// The stride is part of the pool layout: not after SetInput.
+void Circuit::rebuildRelevel() {
+    buildRelevelPlan();
+    uint32_t need = std::max(base_stride_, relevel_stride_);
+    if (inputs_set_ && need > stride_ && balance_) {
+        // the inputs already sit in a pool laid out for a smaller stride: keep the layout, fall back to ASAP placement
+        // (whose temporaries the stride of finalizeNetlist() always covers)
+        balance_ = false;
+        buildRelevelPlan();
+        balance_ = true;
+        need = std::max(base_stride_, relevel_stride_);
+    }
+    if (inputs_set_ && need > stride_) throw std::logic_error("the schedule needs a larger slot stride than the pool was laid out with");
+    if (!inputs_set_) stride_ = need;
+}
+
+// per-step bootstrap counts of the schedule (for one instance), and a self-check: every input of every step was produced
+// by an earlier step (or is a primary input / constant), every XOR temporary is read exactly one step after it is written
+std::vector<uint32_t> Circuit::relevelStepSizes() const {
+    std::vector<uint32_t> v;
+    for (const auto& st : relevel_plan_) v.push_back((uint32_t)st.descs.size());
+    return v;
+}
+
+bool Circuit::checkRelevelPlan(std::string* why) const {
+    const size_t W = wire_names_.size();
+    std::vector<int32_t> written(relevel_stride_, -1);   // step that wrote a slot; inputs and constants: step -1 = "before"
+    std::vector<uint8_t> is_out(W, 0);
+    for (const auto& g : allGates) if ((g.op == GateEnum::AND || g.op == GateEnum::OR || g.op == GateEnum::XOR) && g.out >= 0) is_out[g.out] = 1;
+    auto fail = [&](const std::string& m) { if (why) *why = m; return false; };
+    for (size_t s = 0; s < relevel_plan_.size(); ++s) {
+        for (const auto& d : relevel_plan_[s].descs) {
+            for (uint32_t in : {d.in0, d.in1}) {
+                if (in >= relevel_stride_) return fail("input slot outside the stride");
+                if (in < W) {
+                    if (is_out[in] && (written[in] < 0 || written[in] >= (int32_t)s)) return fail("step " + std::to_string(s) + " reads register " + std::to_string(in) + " before it is written");
+                } else if (written[in] != (int32_t)s - 1) {
+                    return fail("step " + std::to_string(s) + " reads an XOR temporary that was not written in the previous step");
+                }
+            }
+        }
+        for (const auto& d : relevel_plan_[s].descs) {
+            if (d.out >= relevel_stride_) return fail("output slot outside the stride");
+            if (d.out < W && written[d.out] >= 0) return fail("register written twice");
+            if (written[d.out] == (int32_t)s) return fail("slot written twice in one step");
+            written[d.out] = (int32_t)s;
+        }
+    }
+    for (size_t w = 0; w < W; ++w) if (is_out[w] && written[w] < 0) return fail("register " + std::to_string(w) + " never written");
+    return true;
+}
+
 void Circuit::setXorFast(bool b) {
     xor_fast_ = gep.xor_fast = b;
     buildShardPlan();
-    buildRelevelPlan();
+    rebuildRelevel();
+}
+
+void Circuit::setBalance(bool on, uint32_t lone, uint32_t full) {
+    balance_ = on; cap_lone_ = lone; cap_full_ = full;
+    rebuildRelevel();
 }
 
 void Circuit::clockReleveled() {
     if (world_ > 1 && shard_mode_ == 1) throw std::logic_error("re-levelled schedule is not available with gate sharding");
     if (verify_flag) throw std::logic_error("re-levelled schedule is not available in verify mode");
-    if (relevel_plan_.empty()) buildRelevelPlan();
     unsigned lo, hi;
     instanceRange(lo, hi);
     const uint32_t K = hi - lo;
+    if (relevel_plan_.empty() || (balance_ && relevel_K_ != std::max(1u, K))) rebuildRelevel();
     if (relevel_stride_ > stride_) throw std::logic_error("re-levelled schedule needs more scratch slots than the pool stride");
     auto launch = [&](const std::vector<bce_gate_desc>& src) {
         if (src.empty()) return;

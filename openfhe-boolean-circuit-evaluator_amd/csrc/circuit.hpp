@@ -124,6 +124,12 @@ public:
     // ciphertexts as the level schedule (EvalNOT is deterministic), fewer dependent launches.
     void setRelevel(bool b) { relevel_ = b; }
     bool getRelevel() const { return relevel_; }
+    // the bootstrap-depth schedule fills its steps by slack up to the launch staircase of the engine (default on; see
+    // buildRelevelPlan).  lone / full = 0: ask the engine (bce_launch_capacity), else use these capacities (tests).
+    void setBalance(bool on, uint32_t lone = 0, uint32_t full = 0);
+    bool getBalance() const { return balance_; }
+    std::vector<uint32_t> relevelStepSizes() const;          // bootstraps per step, one instance
+    bool checkRelevelPlan(std::string* why = nullptr) const; // every step reads only what earlier steps wrote
     bool getXorFast() const { return xor_fast_; }
     void setQuiet(bool q) { quiet_ = q; }
     // re-arm for another Clock() on the SAME inputs: keeps mode flags and the input ciphertexts
@@ -207,8 +213,12 @@ private:
     bool relevel_ = false;
     std::vector<RStep> relevel_plan_;          // bootstrap-depth schedule (built lazily)
     std::vector<bce_gate_desc> relevel_nots_;  // NOT wires that OUTPUT gates read: materialised at the end
-    uint32_t relevel_stride_ = 0;
+    uint32_t relevel_stride_ = 0, base_stride_ = 0, relevel_K_ = 0;
+    bool balance_ = true;
+    uint32_t cap_lone_ = 0, cap_full_ = 0;
+    void launchCapacity(uint32_t& lone, uint32_t& full) const;
     void buildRelevelPlan();
+    void rebuildRelevel();
     void clockReleveled();
     void managerRound(size_t level);
     void executeRound(size_t level);

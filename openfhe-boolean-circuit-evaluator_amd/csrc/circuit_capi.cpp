@@ -82,6 +82,20 @@ int bce_circuit_set_encrypt_mode(bce_circuit* h, int mode) {
 int bce_circuit_set_xor_fast(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setXorFast(on != 0); }); }
 int bce_circuit_set_relevel(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setRelevel(on != 0); }); }
 int bce_circuit_set_instances(bce_circuit* h, uint32_t k) { return guarded(h, [&] { h->c.setInstances(k); }); }
+int bce_circuit_set_balance(bce_circuit* h, int on, uint32_t lone, uint32_t full) { return guarded(h, [&] { h->c.setBalance(on != 0, lone, full); }); }
+int bce_circuit_relevel_steps(const bce_circuit* h, uint32_t* sizes, uint32_t cap, uint32_t* n_steps) {
+    if (!h || !n_steps || (cap && !sizes)) return BCE_ERR_ARG;
+    const std::vector<uint32_t> v = h->c.relevelStepSizes();
+    for (size_t i = 0; i < v.size() && i < cap; ++i) sizes[i] = v[i];
+    *n_steps = (uint32_t)v.size();
+    return BCE_OK;
+}
+int bce_circuit_check_relevel(bce_circuit* h) {
+    return guarded(h, [&] {
+        std::string why;
+        if (!h->c.checkRelevelPlan(&why)) throw std::logic_error("bootstrap-depth schedule: " + why);
+    });
+}
 
 int bce_circuit_set_input(bce_circuit* h, uint32_t instance, const uint32_t* widths, uint32_t n_buses, const uint8_t* bits) {
     return guarded(h, [&] {

@@ -959,6 +959,25 @@ int bce_timing_get(bce_ctx* c, bce_timing* out) {
 
 uint32_t bce_forward_transforms_per_step(const bce_ctx* c) { return c ? 2 * c->dG - (c->P.fold ? 2 : 0) : 0; }
 
+int bce_launch_capacity(const bce_ctx* c, uint32_t* lone, uint32_t* full) {
+    if (!c || !lone || !full) return BCE_ERR_ARG;
+    const DevParams& P = c->P;
+    const u32 cu = P.cu_count;
+    u32 per_cu;
+    if (c->is64) {
+        // 64-bit kernels: LDS-bound residency (N = 2048: one workgroup per CU)
+        per_cu = (u32)std::max<size_t>(1, (160 * 1024) / blind_rotate64_lds_bytes(P));
+        if (c->logN == 11) per_cu = 1;
+    } else if (P.variant != 1 && c->logN == 10 && c->dG == 4 && P.lazy) {
+        per_cu = 2;                                    // split-transform kernel, 128-register build
+    } else {
+        per_cu = P.occupancy_target;                   // one wave per transform: 2 or 3 workgroups per CU
+    }
+    *lone = cu;
+    *full = cu * per_cu;
+    return BCE_OK;
+}
+
 int bce_bytes_per_bootstrap_parts(const bce_ctx* c, uint64_t out[3]) {
     if (!c || !out) return BCE_ERR_ARG;
     const double rgsws = c->method == BCE_AP ? (double)c->n * c->dR * (c->baseR - 1) / c->baseR : 2.0 * c->n;

@@ -356,3 +356,53 @@ def test_bristol_fashion_eq_mand_three_inputs_two_outputs(bce, tmp_path):
     bad.write_text(BF_MAJ3.replace("4 2 0 1 2 3 7 8 MAND", "3 2 0 1 2 7 8 MAND"))
     with pytest.raises(bce.BceError):
         bce.Circuit().ReadBristol(str(bad), new_flag=True)
+
+
+def _launch_ms(n):
+    """launch-time staircase of the STD128_OPT kernels on one MI355X (profiles/r02_launch_curve.log), for pricing schedules"""
+    if n <= 0:
+        return 0.0
+    if n <= 256:
+        return 1.93 + 0.10 * n / 256
+    full, rem = divmod(n, 512)
+    t = 3.16 * full
+    if rem == 0:
+        return t
+    if full == 0:
+        return 3.03 + 0.13 * (rem - 256) / 256
+    return t + (2.3 if rem <= 256 else 3.16)
+
+
+@pytest.mark.parametrize("name,new_flag,K", [("sha256_new.txt", True, 16), ("AES-expanded.txt", False, 4), ("AES-expanded.txt", False, 1),
+                                              ("adder_64bit.txt", False, 64), ("mult_32x32.txt", False, 8), ("md5.txt", False, 3)])
+def test_balanced_bootstrap_depth_schedule_is_valid_and_cheaper(bce, name, new_flag, K):
+    """The bootstrap-depth schedule fills its steps by slack up to the engine's launch staircase (capacities given
+    explicitly here: 256 / 512 as on an MI355X).  Host-side properties, no GPU: same number of steps and bootstraps as
+    ASAP placement, every step reads only what earlier steps wrote (bce_circuit_check_relevel), and the schedule is never
+    more expensive under the measured launch-time staircase.  That the ciphertexts are identical is a GPU test
+    (tests/test_gpu_circuit.py)."""
+    c = bce.Circuit()
+    c.ReadBristol(os.path.join(CIRCUITS, name), new_flag=new_flag)
+    c.setInstances(K)
+    c.setBalance(False)
+    asap = c.relevel_steps()
+    c.check_relevel()
+    c.setBalance(True, 256, 512)
+    bal = c.relevel_steps()
+    c.check_relevel()
+    info = c.info()
+    assert len(bal) == len(asap) == info["n_relevel_steps"]
+    assert sum(bal) == sum(asap) == info["n_bootstraps"]
+    cost_asap = sum(_launch_ms(n * K) for n in asap)
+    cost_bal = sum(_launch_ms(n * K) for n in bal)
+    assert cost_bal <= cost_asap * 1.0001
+    if name == "sha256_new.txt":
+        assert cost_bal < 0.85 * cost_asap      # 45.0 s -> 36.3 s in this model; measured on the GPU: DESIGN.md 5
+    # K beyond the capacities and a capacity of one: still valid
+    c.setInstances(1000)
+    c.check_relevel()
+    c.setInstances(1)
+    c.setBalance(True, 1, 1)
+    c.check_relevel()
+    assert c.relevel_steps() == asap or sum(c.relevel_steps()) == sum(asap)
+    c.close()
