@@ -19,11 +19,16 @@ CONFIGS = [
     ("1 adder_2bit TOY GINX", "adder_2bit.out", "out", "TOY", "GINX", [1]),
     ("2 adder_64bit STD128_OPT GINX", "adder_64bit.txt", "old", "STD128_OPT", "GINX", [1, 64, 256]),
     ("3 AES-expanded STD128_OPT GINX", "AES-expanded.txt", "old", "STD128_OPT", "GINX", [1, 16]),
-    ("3r AES-expanded STD128_OPT GINX bootstrap-depth schedule", "AES-expanded.txt", "old", "STD128_OPT", "GINX", [1, 32]),
+    ("2r adder_64bit STD128_OPT GINX bootstrap-depth schedule", "adder_64bit.txt", "old", "STD128_OPT", "GINX", [64, 256]),
+    ("2u adder_64bit STD128_OPT GINX bootstrap-depth schedule, ASAP placement (balance off)", "adder_64bit.txt", "old", "STD128_OPT", "GINX", [64, 256]),
+    ("3r AES-expanded STD128_OPT GINX bootstrap-depth schedule", "AES-expanded.txt", "old", "STD128_OPT", "GINX", [1, 2, 4, 8, 32]),
+    ("3u AES-expanded STD128_OPT GINX bootstrap-depth schedule, ASAP placement (balance off)", "AES-expanded.txt", "old", "STD128_OPT", "GINX", [1, 2, 4, 8, 32]),
     ("4 sha256 (new format) STD128_OPT GINX", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
     ("4r sha256 (new format) STD128_OPT GINX bootstrap-depth schedule", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
+    ("4u sha256 (new format) STD128_OPT GINX bootstrap-depth schedule, ASAP placement (balance off)", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
     ("5 adder_64bit STD192 AP", "adder_64bit.txt", "old", "STD192", "AP", [64]),
     ("5b AES-expanded STD192 AP", "AES-expanded.txt", "old", "STD192", "AP", [2, 8]),
+    ("5r AES-expanded STD192 AP bootstrap-depth schedule", "AES-expanded.txt", "old", "STD192", "AP", [2, 8]),
 ]
 
 
@@ -49,6 +54,8 @@ def main():
                 c.ReadBristol(path, new_flag=(kind == "new"))
             info = c.info()
             c.setInstances(K)
+            if "balance off" in name:
+                c.setBalance(False)
             rng = np.random.default_rng(1)
             ins = [[rng.integers(0, 2, w).tolist() for w in info["n_input_bits"] if w] for _ in range(K)]
             c.Reset(); c.setPlaintext(True)
@@ -59,6 +66,9 @@ def main():
             c.Reset(); c.setEncrypted(True)
             if "bootstrap-depth" in name:
                 c.setRelevel(True)
+            sched_steps = None
+            if "bootstrap-depth" in name:
+                sched_steps = len(c.relevel_steps())
             for k in range(K):
                 c.SetInput(ins[k], instance=k)
             c.Clock()                      # warm-up
@@ -71,6 +81,8 @@ def main():
             row = {"config": name, "K": K, "bootstraps_per_eval": info["n_bootstraps"], "sublaunches": info["n_sublaunches"],
                    "seconds": round(dt, 3), "bootstraps_per_s": round(st["bootstraps"] / dt), "ms_per_sublaunch": round(dt / max(1, st["sublaunches"]) * 1e3, 3),
                    "correct": ok}
+            if sched_steps is not None:
+                row["sublaunches"] = st["sublaunches"]
             rows.append(row)
             print(json.dumps(row), flush=True)
             c.close()
