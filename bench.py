@@ -383,7 +383,7 @@ def main():
                                 args.circuit, info["n_gates"] - info["n_output_bits"], info["n_bootstraps"],
                                 info["n_sublaunches"], args.paramset, args.instances),
                 "instances_per_gpu": args.instances, "sharding": args.shard,
-                "schedule": "bootstrap-depth levels (NOTs folded, identical ciphertexts)" if R["relevel"] else "gate levels (reference Clock rounds)",
+                "schedule": "bootstrap-depth levels (NOTs folded, steps filled by slack up to the launch staircase, identical ciphertexts)" if R["relevel"] else "gate levels (reference Clock rounds)",
                 "xor": "XOR_FAST (opt-in, 1 bootstrap)" if args.xor_fast else "NOT,NOT,AND,AND,OR (reference, 3 bootstraps)",
                 "bootstraps_per_step": int(total_boot / args.steps),
                 "forward_transforms_per_blind_rotation_step": cc.forward_transforms_per_step(),
