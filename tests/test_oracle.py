@@ -191,3 +191,94 @@ def test_signed_digit_decompose_is_exact_where_the_engine_folds_the_lowest_digit
         # only residues above the largest representable value lose their carry
         assert all(int(v) > hi and int(v) < (Q >> 1) for v in ct[bad])
     o.close()
+
+
+def _negacyclic(a, b, N, Q):
+    """a * b mod (X^N + 1, Q) from the definition (np.convolve, no transform).  a: small signed digits (|a| < 2^10),
+    b: residues < 2^28, so every partial sum stays below 2^48 in int64."""
+    full = np.convolve(a.astype(np.int64), b.astype(np.int64))
+    lo, hi = full[:N].copy(), full[N:]
+    lo[:hi.size] -= hi
+    return lo % Q
+
+
+def _rotate_minus_one(p, k, N, Q):
+    """p(X) * (X^k - 1) mod (X^N + 1, Q), k in [0, 2N)"""
+    k %= 2 * N
+    sign = 1
+    if k >= N:
+        k -= N
+        sign = -1
+    r = np.empty_like(p)
+    r[k:] = p[:N - k]
+    r[:k] = -p[N - k:] if k else p[:0]
+    return (sign * r - p) % Q
+
+
+@pytest.mark.parametrize("method", ["GINX", "AP"])
+def test_blind_rotation_equals_its_coefficient_domain_definition(orc, method):
+    """An independent restatement of BootstrapGateCore + EvalAcc with NO number-theoretic transform anywhere: the
+    accumulator stays in coefficient form, SignedDigitDecompose is re-implemented here in numpy, every RGSW product is a
+    negacyclic convolution by definition (np.convolve) against the COEFFICIENT-form key the oracle exports, the GINX
+    monomials are coefficient rotations.  It must reproduce the oracle's accumulator word for word (TOY, a few gates) --
+    this pins the oracle's transform-domain machinery (CT/GS order, twiddles, evaluation-form keys and monomials, Barrett
+    folds) to the ring arithmetic it stands for.  It does not pin the oracle to OpenFHE (still unpinned: see the header)."""
+    o = orc.Oracle(orc.TOY, getattr(orc, method))
+    o.keygen(424242)
+    P = o.params
+    n, N, q, Q, B, dG = P["n"], o.N, P["q"], P["Q"], P["baseG"], P["dG"]
+    R, factor = 2 * dG, 2 * N // q
+    words = 2 * N
+    bsk = o.bsk().astype(np.int64)
+    gate_const = {orc.OR: 5 * q // 8, orc.AND: 7 * q // 8, orc.NOR: q // 8, orc.NAND: 3 * q // 8}
+
+    def decompose(acc):
+        d = np.where(acc < (Q >> 1), acc, acc - Q).astype(np.int64)          # representative of rgsw-acc.cpp
+        out = []
+        for _ in range(dG):
+            r = ((d + B // 2) % B) - B // 2                                    # signed remainder in [-B/2, B/2)
+            d = (d - r) // B
+            out.append(r)
+        return out                                                             # out[l][c]
+
+    for gate, bits in ((orc.AND, (1, 1)), (orc.NOR, (0, 1)), (orc.NAND, (1, 0))):
+        ca, cb = o.encrypt(bits[0], 900 + gate), o.encrypt(bits[1], 950 + gate)
+        prep = o.gate_prep(gate, ca, cb)
+        b = int(prep[n])
+        q1 = gate_const[gate]
+        q2 = (q1 + q // 2) % q
+        acc = np.zeros((2, N), dtype=np.int64)
+        for j in range(q // 2):
+            t = (b - j) % q
+            inside = (q1 <= t < q2) if q1 < q2 else not (q2 <= t < q1)
+            acc[1, j * factor] = (Q - (Q // 8 + 1)) if inside else (Q // 8 + 1)
+        for i in range(n):
+            aI = (q - int(prep[i])) % q
+            if method == "GINX":
+                steps = [((i * 2 + 0, i * 2 + 1), aI * factor)]
+            else:
+                steps, t = [], aI
+                for k in range(P["dR"]):
+                    a0 = t % P["baseR"]
+                    t //= P["baseR"]
+                    if a0:
+                        steps.append((((i * P["baseR"] + a0) * P["dR"] + k,), None))
+            for keys, rot in steps:
+                dct = decompose(acc)
+                prods = []
+                for key in keys:
+                    ek = bsk[key * R * words:(key + 1) * R * words].reshape(R, 2, N)
+                    p = np.zeros((2, N), dtype=np.int64)
+                    for l in range(dG):
+                        for c in range(2):
+                            for col in range(2):
+                                p[col] = (p[col] + _negacyclic(dct[l][c], ek[2 * l + c, col], N, Q)) % Q
+                    prods.append(p)
+                if method == "GINX":
+                    for col in range(2):
+                        acc[col] = (acc[col] + _rotate_minus_one(prods[0][col], rot, N, Q)
+                                    + _rotate_minus_one(prods[1][col], 2 * N - rot, N, Q)) % Q
+                else:
+                    acc = prods[0]
+        assert np.array_equal(acc.astype(np.uint64), o.blind_rotate(gate, prep).reshape(2, N)), "gate %d" % gate
+    o.close()
