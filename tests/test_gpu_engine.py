@@ -601,3 +601,37 @@ def test_std128_plain_key_split_kernels_and_folded_key_round_trip(std128, bce, v
 def test_toy_keeps_the_plain_key(toy):
     """TOY's gadget (27-bit Q, 3 digits base 2^9) is not exact (tests/test_oracle.py): no folding there."""
     assert toy[1].forward_transforms_per_step() == 6 == 2 * toy[0].params["dG"]
+
+
+def test_std128_saturated_launch_of_distinct_gates_equals_oracle(std128, bce):
+    """One saturated launch (two workgroups per CU, folded key, tail fused into the epilogue) of 768 gates on 1,536
+    DISTINCT fresh ciphertexts -- every operation, folded EvalNOTs on either input, refreshes -- against the oracle's
+    batched evaluation (OpenMP over gates) of the same descriptors: identical final ciphertexts.  The stage-level tests
+    above replicate a handful of inputs; this one walks 768 different accumulator trajectories through the kernel."""
+    o, c = std128
+    rng = np.random.default_rng(20260)
+    nb = 768
+    bits = rng.integers(0, 2, size=2 * nb)
+    cts = np.stack([o.encrypt(int(bits[i]), 50000 + i) for i in range(2 * nb)])
+    c.pool_reserve(3 * nb)
+    c.lwe_write(np.arange(2 * nb, dtype=np.uint32), cts)
+    ops = [bce.OR, bce.AND, bce.NOR, bce.NAND, bce.XOR_FAST, bce.XNOR_FAST, bce.OP_REFRESH]
+    descs = []
+    for i in range(nb):
+        op = ops[int(rng.integers(0, len(ops)))]
+        n0, n1 = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        descs.append((op, 2 * i, 2 * i + 1, 2 * nb + i, n0, n1 if op != bce.OP_REFRESH else 0))
+    t0 = c.timing()["fused_tail_launches"]
+    c.EvalGates(bce.make_descs(descs))
+    got = c.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32))
+    assert c.timing()["fused_tail_launches"] == t0 + 1
+    pool = np.zeros((3 * nb, o.params["n"] + 1), dtype=np.uint64)
+    pool[:2 * nb] = cts
+    o.eval_gates(pool, descs)
+    assert np.array_equal(got, pool[2 * nb:])
+    # and they decrypt to the gate functions
+    for i in (0, 1, 2, nb - 1):
+        op, _, _, _, n0, n1 = descs[i]
+        a, b = int(bits[2 * i]) ^ n0, int(bits[2 * i + 1]) ^ n1
+        want = a if op == bce.OP_REFRESH else _truth(op, a, b)
+        assert o.decrypt(got[i]) == want
