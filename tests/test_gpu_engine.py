@@ -459,6 +459,20 @@ def test_std192_gate_same_seed_keys(bce, orc, method):
     assert np.array_equal(out[0], o.eval_bingate(bce.AND, ca, cb))
     assert np.array_equal(out[1], o.eval_bingate(bce.OR, ca, cb))
     assert list(c.Decrypt([2, 3])) == [0, 1]
+    # 48 gates on distinct ciphertexts in one launch (every operation, folded EvalNOTs) against the oracle's batched evaluation
+    rng = np.random.default_rng(192)
+    nb = 48
+    bits = rng.integers(0, 2, size=2 * nb)
+    cts = np.stack([o.encrypt(int(bits[i]), 700 + i) for i in range(2 * nb)])
+    c.pool_reserve(3 * nb)
+    c.lwe_write(np.arange(2 * nb, dtype=np.uint32), cts)
+    descs = [(int(rng.integers(0, 6)), 2 * i, 2 * i + 1, 2 * nb + i, int(rng.integers(0, 2)), int(rng.integers(0, 2))) for i in range(nb)]
+    c.EvalGates(bce.make_descs(descs))
+    pool = np.zeros((3 * nb, o.params["n"] + 1), dtype=np.uint64)
+    pool[:2 * nb] = cts
+    o.eval_gates(pool, descs)
+    assert np.array_equal(c.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32)), pool[2 * nb:])
+    assert c.forward_transforms_per_step() == 4
     o.close()
     c.close()
 
