@@ -23,6 +23,8 @@ CONFIGS = [
     ("2u adder_64bit STD128_OPT GINX bootstrap-depth schedule, ASAP placement (balance off)", "adder_64bit.txt", "old", "STD128_OPT", "GINX", [64, 256]),
     ("3r AES-expanded STD128_OPT GINX bootstrap-depth schedule", "AES-expanded.txt", "old", "STD128_OPT", "GINX", [1, 2, 4, 8, 32]),
     ("3u AES-expanded STD128_OPT GINX bootstrap-depth schedule, ASAP placement (balance off)", "AES-expanded.txt", "old", "STD128_OPT", "GINX", [1, 2, 4, 8, 32]),
+    ("3n AES-non-expanded (33,616 gates) STD128_OPT GINX bootstrap-depth schedule", "AES-non-expanded.txt", "old", "STD128_OPT", "GINX", [1, 16]),
+    ("3m md5 STD128_OPT GINX bootstrap-depth schedule", "md5.txt", "old", "STD128_OPT", "GINX", [16]),
     ("4 sha256 (new format) STD128_OPT GINX", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
     ("4r sha256 (new format) STD128_OPT GINX bootstrap-depth schedule", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
     ("4u sha256 (new format) STD128_OPT GINX bootstrap-depth schedule, ASAP placement (balance off)", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
