@@ -1261,7 +1261,9 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
         // workgroup's latency-bound phases (inverse passes, MAC tail) get their issue slots first and the transform
         // waves fill the gaps (+1..4 %, same-box A/B; the opposite policy costs 7 %, and a lone workgroup loses 6 %
         // with either, hence only in this build)
-        if constexpr (WPS >= 4) __builtin_amdgcn_s_setprio(0);
+        // (folded key: the half-row waves 4..7 -- the younger ones, which the arbiter serves last -- one level above the
+        // whole-row waves, so that both kinds finish the phase together: -2 % per saturated launch, profiles/r02_prio_ab.log)
+        if constexpr (WPS >= 4) { if (FOLD && wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         if constexpr (FOLD) {
             // six rows (2..7) on eight waves: whole rows 2..5 on waves 0..3, rows 6 and 7 as halves on waves 4..7
             if (wave < 4) ntt_forward_wave_low8(dct + (2 + wave) * NP, twf, lane, Q);
