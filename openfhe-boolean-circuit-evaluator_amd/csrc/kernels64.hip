@@ -740,6 +740,79 @@ __device__ __forceinline__ void forward_half(double* poly, Tw twa, u32 v, double
             for (int r = 0; r < 16; ++r) poly[phys(base | (u32)r)] = x[r];
         }
 }
+// One QUARTER of a forward transform (N = 2048; stages on bits 7..0, bits 10, 9, 8 were applied by the producer) by one
+// wave: positions [512 k, 512 k + 512) are two of the eight independent 256-point sub-transforms of the row, so the
+// wave needs nobody else's data -- 64 lanes x 8 coefficients, passes on bits 7..5 / 4..2 / 1..0, two WAVE-LOCAL
+// re-shuffles, no workgroup barrier.  The folded 16-wave kernel runs its four digit rows as 16 of these, one per wave
+// (four per SIMD); the folded 8-wave kernel runs two per wave.
+__device__ __forceinline__ void fwd_bfly_d(double& X, double& Y, double2 w, double Q) {
+    const double T = modmul_q(Y, w.x, w.y, Q);
+    Y = X - T;
+    X = X + T;
+}
+template <int LOGN>
+__device__ __forceinline__ void forward_quarter(double* row, u32 k, Tw twa, u32 lane, double Q) {
+    static_assert(LOGN == 11, "laid out for N = 2048");
+    const double2* twl = twa.l;   // blocks m <= 512 sit in the LDS mirror, the block of the last stage (m = 1024) in global memory
+    double x[8];
+    {   // coefficients = bits 7..5, lane = (bit 8, bits 4..0)
+        const u32 l8 = lane >> 5, hi = (k << 1) | l8;
+        double* const p = row + phys((k << 9) | (l8 << 8) | (lane & 31u));   // coefficient r: + 32 r
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = p[(r >> 1) * 68 + (r & 1) * 32];
+        const double2 w7 = twl[8 + hi];                                       // stage on bit B: tw[m + (p >> (B + 1))], m = 2^(10 - B)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fwd_bfly_d(x[r], x[r + 4], w7, Q);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const double2 w6 = twl[16 + ((hi << 1) | g)];
+            fwd_bfly_d(x[4 * g], x[4 * g + 2], w6, Q);
+            fwd_bfly_d(x[4 * g + 1], x[4 * g + 3], w6, Q);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fwd_bfly_d(x[2 * g], x[2 * g + 1], twl[32 + ((hi << 2) | g)], Q);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) p[(r >> 1) * 68 + (r & 1) * 32] = x[r];
+    }
+    wave_sync();
+    {   // coefficients = bits 4..2, lane = (bits 8..5, bits 1..0)
+        const u32 lh = lane >> 2, hi = (k << 4) | lh;
+        double* const p = row + phys((k << 9) | (lh << 5) | (lane & 3u));       // coefficient r: + 4 r, inside one 64-block
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = p[4 * r];
+        const double2 w4 = twl[64 + hi];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fwd_bfly_d(x[r], x[r + 4], w4, Q);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const double2 w3 = twl[128 + ((hi << 1) | g)];
+            fwd_bfly_d(x[4 * g], x[4 * g + 2], w3, Q);
+            fwd_bfly_d(x[4 * g + 1], x[4 * g + 3], w3, Q);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fwd_bfly_d(x[2 * g], x[2 * g + 1], twl[256 + ((hi << 2) | g)], Q);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) p[4 * r] = x[r];
+    }
+    wave_sync();
+    {   // coefficients = bits 2..0 (bit 2 is done): 8 consecutive words per lane
+        const u32 hl = (k << 6) | lane;
+        double2* const p = reinterpret_cast<double2*>(row + phys(hl << 3));
+        const double2 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+        x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y; x[6] = v3.x; x[7] = v3.y;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const double2 w1 = twl[512 + ((hl << 1) | g)];
+            fwd_bfly_d(x[4 * g], x[4 * g + 2], w1, Q);
+            fwd_bfly_d(x[4 * g + 1], x[4 * g + 3], w1, Q);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fwd_bfly_d(x[2 * g], x[2 * g + 1], twa.g[1024 + ((hl << 2) | g)], Q);
+        p[0] = make_double2(x[0], x[1]); p[1] = make_double2(x[2], x[3]); p[2] = make_double2(x[4], x[5]); p[3] = make_double2(x[6], x[7]);
+    }
+    wave_sync();
+}
+
 // Forward phase of the 16-wave (N = 2048) workgroup: the 6 digit polynomials as 12 half-transforms on waves 0..11
 // (three per SIMD); waves 12..15 only take part in the barrier.
 template <int LOGN>
@@ -902,8 +975,8 @@ __device__ __forceinline__ void split_inverse11(const double* src, double* bufA,
 // FOLD (with SPLIT): the lowest gadget digit is never transformed -- the key arrives with rows l >= 1 replaced by
 // ek_l - B^l ek_0 and the MAC multiplies the digit-0 rows by the evaluation-form accumulator itself (see the FOLD note of
 // k_blind_rotate_lat in kernels.hip; SignedDigitDecompose is exact for these parameters, checked by the host).  Four
-// forward transforms per step instead of six = eight half-transforms, one per wave (two per SIMD; 16-wave build: waves
-// 0..7).  The accumulator is double-buffered between `acc` and digit rows 0, 1; the inverse transform's exchange buffers
+// forward transforms per step instead of six = eight half-transforms, one per wave (8-wave build), or sixteen quarter-
+// transforms, one per wave (16-wave build).  The accumulator is double-buffered between `acc` and digit rows 0, 1; the inverse transform's exchange buffers
 // move to digit rows 2..5.
 template <int LOGN, int DG, bool AP, bool SPLIT = false, bool W16 = false, bool FOLD = false,
           u32 NBUF_ = (W16 ? (AP ? BCE_W16_NBUF_AP : BCE_W16_NBUF_GINX) : (AP ? 3 : 2)),
@@ -1104,10 +1177,14 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
         BCE_PROF_MARK(0);
         block_sync_lds();
         BCE_PROF_MARK(1);
-        if constexpr (FOLD) {
-            // rows 2..5 as eight half-transforms: waves w and w + 4 share a row (and a SIMD)
-            if (wave < 8) forward_half<LOGN>(dct + (2 + (wave & 3u)) * NP, twa, (wave >> 2) * 64u + lane_v, Q);
-            else block_sync_lds();
+        if constexpr (FOLD && W16) {
+            // rows 2..5 as sixteen quarter-transforms, one per wave (four per SIMD), no barrier inside the phase (eight
+            // half-transforms on waves 0..7 with waves 8..15 idle: 21.0 vs 20.2 ms per launch, profiles/r02_fold_quarters_ab.log)
+            forward_quarter<LOGN>(dct + (2 + (wave & 3u)) * NP, wave >> 2, twa, lane_v, Q);
+        } else if constexpr (FOLD) {
+            // eight waves: rows 2..5 as eight half-transforms, waves w and w + 4 share a row (and a SIMD); two quarter-
+            // transforms per wave instead measure the same
+            forward_half<LOGN>(dct + (2 + (wave & 3u)) * NP, twa, (wave >> 2) * 64u + lane_v, Q);
         } else if constexpr (W16) {
             forward_phase_halves<LOGN>(dct, NP, twa, wave, lane_v, Q);
         } else if constexpr (SPLIT) {
