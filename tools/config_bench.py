@@ -26,7 +26,7 @@ CONFIGS = [
     ("3n AES-non-expanded (33,616 gates) STD128_OPT GINX bootstrap-depth schedule", "AES-non-expanded.txt", "old", "STD128_OPT", "GINX", [1, 16]),
     ("3m md5 STD128_OPT GINX bootstrap-depth schedule", "md5.txt", "old", "STD128_OPT", "GINX", [16]),
     ("4 sha256 (new format) STD128_OPT GINX", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
-    ("4r sha256 (new format) STD128_OPT GINX bootstrap-depth schedule", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
+    ("4r sha256 (new format) STD128_OPT GINX bootstrap-depth schedule", "sha256_new.txt", "new", "STD128_OPT", "GINX", [1, 4, 8, 16, 32]),
     ("4u sha256 (new format) STD128_OPT GINX bootstrap-depth schedule, ASAP placement (balance off)", "sha256_new.txt", "new", "STD128_OPT", "GINX", [16]),
     ("5 adder_64bit STD192 AP", "adder_64bit.txt", "old", "STD192", "AP", [64]),
     ("5b AES-expanded STD192 AP", "AES-expanded.txt", "old", "STD192", "AP", [2, 8]),
