@@ -649,3 +649,36 @@ def test_std128_saturated_launch_of_distinct_gates_equals_oracle(std128, bce):
         a, b = int(bits[2 * i]) ^ n0, int(bits[2 * i + 1]) ^ n1
         want = a if op == bce.OP_REFRESH else _truth(op, a, b)
         assert o.decrypt(got[i]) == want
+
+
+@pytest.mark.parametrize("ps,fwd", [("STD128", 6), ("STD192_OPT", 4), ("STD128_APOPT", 6), ("MEDIUM", 6)])
+def test_other_parameter_sets_of_the_table_same_seed_keys(bce, orc, ps, fwd):
+    """The remaining rows of OpenFHE's parameter table that the kernels cover, GINX: STD128 (n = 512) runs the folded
+    split-transform kernel like STD128_OPT, STD192_OPT (n = 805, qKS = 2^15) the folded N = 2048 doubles kernel;
+    STD128_APOPT (27-bit Q, 3 digits base 2^9: gadget not exact) and MEDIUM (28-bit Q: non-lazy path) stay on the
+    one-wave-per-transform kernel with the plain key.  Engine keygen from the seed the oracle uses (keygen parity is
+    established above), 12 gates on distinct ciphertexts vs the oracle's batched evaluation."""
+    o = orc.Oracle(getattr(orc, ps), orc.GINX)
+    o.keygen(1618)
+    c = bce.BinFHEContext(getattr(bce, ps), bce.GINX)
+    c.KeyGen(1618)
+    assert o.params == c.params
+    assert c.forward_transforms_per_step() == fwd
+    rng = np.random.default_rng(7)
+    nb = 12
+    bits = rng.integers(0, 2, size=2 * nb)
+    cts = np.stack([o.encrypt(int(bits[i]), 300 + i) for i in range(2 * nb)])
+    c.pool_reserve(3 * nb)
+    c.lwe_write(np.arange(2 * nb, dtype=np.uint32), cts)
+    descs = [(i % 6, 2 * i, 2 * i + 1, 2 * nb + i, int(rng.integers(0, 2)), int(rng.integers(0, 2))) for i in range(nb)]
+    c.EvalGates(bce.make_descs(descs))
+    pool = np.zeros((3 * nb, o.params["n"] + 1), dtype=np.uint64)
+    pool[:2 * nb] = cts
+    o.eval_gates(pool, descs)
+    got = c.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32))
+    assert np.array_equal(got, pool[2 * nb:])
+    for i in range(nb):
+        op, _, _, _, n0, n1 = descs[i]
+        assert o.decrypt(got[i]) == _truth(op, int(bits[2 * i]) ^ n0, int(bits[2 * i + 1]) ^ n1)
+    o.close()
+    c.close()
