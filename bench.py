@@ -187,7 +187,6 @@ def main():
             circ.setXorFast(True)
         gates = world > 1 and shard_mode == 1
         if gates:
-            relevel = False        # the bootstrap-depth schedule is not defined for gate sharding: reference gate levels
             cc.set_encrypt_seed(0x0FE5EED)   # every rank must encrypt IDENTICAL input ciphertexts
         if relevel:
             circ.setRelevel(True)
@@ -429,7 +428,7 @@ def main():
         try:        # a failure of the secondary run must not cost the headline line
             if os.environ.get("BCE_BENCH_TEST_HANG") == "1" and rank == world - 1:
                 time.sleep(1e6)      # test hook (tests/test_bench_launch.py): one rank never reaches the collective
-            G = run_mode(1, args.gates_steps, 1, False)
+            G = run_mode(1, args.gates_steps, 1, args.relevel)
         except Exception as e:
             G_err = repr(e)
     if rank == 0:
@@ -437,8 +436,10 @@ def main():
             out["shard_gates"] = {"error": G_err}
         if G is not None:
             out["shard_gates"] = {
-                "what": "the same circuit and K, every level's gates split over the %d ranks by bootstrap weight (north_star's partition); "
-                        "boundary ciphertexts exchanged with one allgather per level (%s); reference gate-level schedule" % (world, backend),
+                "what": "the same circuit and K, every step's gates split over the %d ranks by bootstrap weight (north_star's partition); "
+                        "boundary ciphertexts exchanged with one allgather per step (%s); %s" % (
+                            world, backend, "bootstrap-depth schedule, steps filled by slack up to the staircase of all ranks together"
+                            if G["relevel"] else "reference gate-level schedule"),
                 "value": G["total_boot"] / G["elapsed"], "unit": "gate-bootstraps/s", "scaling": "strong",
                 "ms_per_step": G["elapsed"] / G["steps"] * 1e3, "steps": G["steps"], "warmup": 1,
                 "exchanges_per_step": G["exchanges_per_step"], "exchanged_cts_per_step": G["exchanged_cts_per_step"],

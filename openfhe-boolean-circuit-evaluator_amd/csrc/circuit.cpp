@@ -526,6 +526,12 @@ uint64_t Circuit::exchangeCapacity(uint32_t world, int shard_mode, bool encrypte
     uint64_t widest = 0;
     for (const auto& lv : xwires_) for (const auto& r : lv) widest = std::max<uint64_t>(widest, r.size());
     if (xwires_.empty()) for (const auto& lv : levels_) widest = std::max<uint64_t>(widest, lv.gates.size());
+    // bootstrap-depth schedule under gate sharding: per-step publications (before the plan exists for this world: a step's
+    // outputs are at most its descriptors; slack filling under a larger world can widen steps up to the whole circuit's width)
+    for (const auto& st : relevel_xw_) for (const auto& r : st) widest = std::max<uint64_t>(widest, r.size());
+    if (relevel_xw_.empty()) for (const auto& st : relevel_plan_) widest = std::max<uint64_t>(widest, st.descs.size());
+    // (callers size their buffers with this BEFORE set_exchange and ask again afterwards: the plan for the new world may
+    // publish more per step than the estimate -- dist.Exchange does)
     return std::max<uint64_t>(64, widest * instances_ * (encrypted ? W : 1));
 }
 
@@ -544,10 +550,16 @@ void Circuit::setExchange(uint32_t rank, uint32_t world, int shard_mode, bce_all
 // after a level: publish wires whose consumers sit on other ranks (shard_mode 1)
 void Circuit::exchangeLevel(size_t level) {
     if (world_ <= 1 || shard_mode_ != 1) return;
+    exchangeWires(xwires_[level]);
+}
+
+// one exchange: pub[r] = the wires rank r publishes (every rank knows every list: the plan is static)
+void Circuit::exchangeWires(const std::vector<std::vector<int>>& pub) {
+    if (world_ <= 1 || shard_mode_ != 1) return;
     size_t widest = 0;
-    for (uint32_t r = 0; r < world_; ++r) widest = std::max(widest, xwires_[level][r].size());
+    for (uint32_t r = 0; r < world_; ++r) widest = std::max(widest, pub[r].size());
     if (widest == 0) return;
-    const auto& mine = xwires_[level][rank_];
+    const auto& mine = pub[rank_];
     const unsigned K = instances_;
     if (plaintext_flag) {
         const uint64_t bytes = (uint64_t)widest * K;
@@ -559,7 +571,7 @@ void Circuit::exchangeLevel(size_t level) {
         const uint8_t* rcv = (const uint8_t*)host_recv_;
         for (uint32_t r = 0; r < world_; ++r) {
             if (r == rank_) continue;
-            const auto& theirs = xwires_[level][r];
+            const auto& theirs = pub[r];
             for (unsigned i = 0; i < K; ++i) for (size_t k = 0; k < theirs.size(); ++k) plain_[i][theirs[k]] = rcv[(uint64_t)r * bytes + i * widest + k];
         }
         ++stats_.exchanges;
@@ -582,7 +594,7 @@ void Circuit::exchangeLevel(size_t level) {
         }
         for (uint32_t r = 0; r < world_; ++r) {
             if (r == rank_) continue;
-            const auto& theirs = xwires_[level][r];
+            const auto& theirs = pub[r];
             if (theirs.empty()) continue;
             // rows [i][k<theirs.size()] of rank r's block
             for (unsigned i = 0; i < K; ++i) {
@@ -640,7 +652,7 @@ void Circuit::buildRelevelPlan() {
     for (size_t w = 0; w < W; ++w) base[w] = (int)w;
     // gates are in topological (file) order per level; walk levels so that bases are resolved first
     std::vector<uint32_t> depth(W, 0);
-    struct Unit { uint32_t asap, start; uint8_t lat; bce_gate_desc d; int32_t p0, p1; };   // XOR: d holds (in0, in1, out, n0, n1)
+    struct Unit { uint32_t asap, start; uint8_t lat, owner; bce_gate_desc d; int32_t p0, p1; };   // XOR: d holds (in0, in1, out, n0, n1)
     std::vector<Unit> units;
     std::vector<int32_t> prod(W, -1);   // base wire -> unit that produces it
     units.reserve(G);
@@ -655,7 +667,7 @@ void Circuit::buildRelevelPlan() {
                 const uint32_t b0 = (uint32_t)base[g.in[0]], b1 = (uint32_t)base[g.in[1]];
                 const uint32_t n0 = neg[g.in[0]], n1 = neg[g.in[1]];
                 const uint32_t d = 1 + std::max(depth[g.in[0]], depth[g.in[1]]);
-                Unit u{d, d, 1, {0, b0, b1, (uint32_t)g.out, n0, n1}, prod[b0], prod[b1]};
+                Unit u{d, d, 1, 0, {0, b0, b1, (uint32_t)g.out, n0, n1}, prod[b0], prod[b1]};
                 if (g.op != GateEnum::XOR) {
                     u.d.op = (uint32_t)(g.op == GateEnum::AND ? BCE_AND : BCE_OR);
                 } else if (xor_fast_) {
@@ -676,9 +688,11 @@ void Circuit::buildRelevelPlan() {
     unsigned ilo, ihi;
     instanceRange(ilo, ihi);
     const uint64_t K = std::max(1u, ihi - ilo);
+    const bool sharded = world_ > 1 && shard_mode_ == 1;   // gate sharding: every step's units are split over the ranks
     if (balance_ && U) {
         uint32_t lone, full;
         launchCapacity(lone, full);
+        if (sharded) { lone *= world_; full *= world_; }   // the stairs of world_ devices working on one step
         // successors (CSR) and ALAP start steps (units are in topological order)
         std::vector<uint32_t> soff(U + 1, 0), succ;
         for (const auto& u : units) { if (u.p0 >= 0) ++soff[u.p0 + 1]; if (u.p1 >= 0 && u.p1 != u.p0) ++soff[u.p1 + 1]; }
@@ -740,15 +754,61 @@ void Circuit::buildRelevelPlan() {
         }
         if (!ready.empty()) throw std::logic_error("buildRelevelPlan: units left unscheduled");
     }
+    // gate sharding: the units that start in a step are split over the ranks in netlist order by bootstrap weight (an XOR's
+    // three bootstraps stay on one rank: its temporaries are local), on top of the ORs each rank carries over from the
+    // previous step.  Every rank computes the same plan.
+    relevel_xw_.clear();
+    if (sharded) {
+        std::vector<std::vector<uint32_t>> by_step(D + 2);
+        for (size_t i = 0; i < U; ++i) by_step[units[i].start].push_back((uint32_t)i);
+        std::vector<uint64_t> carried(world_, 0), next_carried(world_, 0);
+        for (uint32_t st = 1; st <= D; ++st) {
+            uint64_t total = 0;
+            for (uint32_t r = 0; r < world_; ++r) total += carried[r];
+            for (uint32_t i : by_step[st]) total += units[i].lat == 2 ? 2 : 1;
+            std::fill(next_carried.begin(), next_carried.end(), 0);
+            // contiguous split in netlist order: rank r ends where the running load (carried ORs of ranks <= r + the units
+            // given out so far) reaches (r + 1) / world of the step's total (midpoint rule: within one unit of the fair share)
+            uint32_t r = 0;
+            uint64_t cum = carried[0];
+            for (uint32_t i : by_step[st]) {
+                const uint64_t w = units[i].lat == 2 ? 2 : 1;
+                while (r + 1 < world_ && (2 * cum + w) * world_ > 2 * (uint64_t)(r + 1) * total) { ++r; cum += carried[r]; }
+                units[i].owner = (uint8_t)r;
+                cum += w;
+                if (units[i].lat == 2) ++next_carried[r];
+            }
+            carried.swap(next_carried);
+        }
+        // publications: an output crosses when a consumer unit sits on another rank, or when an OUTPUT gate reads it (every
+        // rank decrypts every output, as in the gate-level plan); it is published after the step that produces it
+        std::vector<uint8_t> feeds_output(W, 0);
+        for (const auto& g : allGates) if (g.op == GateEnum::OUTPUT) feeds_output[base[g.in[0]]] = 1;
+        std::vector<uint8_t> cross(U, 0);
+        for (size_t i = 0; i < U; ++i) {
+            const Unit& u = units[i];
+            if (u.p0 >= 0 && units[u.p0].owner != u.owner) cross[u.p0] = 1;
+            if (u.p1 >= 0 && units[u.p1].owner != u.owner) cross[u.p1] = 1;
+            if (feeds_output[u.d.out]) cross[i] = 1;
+        }
+        relevel_xw_.assign(D, std::vector<std::vector<int>>(world_));
+        for (size_t i = 0; i < U; ++i)
+            if (cross[i]) relevel_xw_[units[i].start + units[i].lat - 2][units[i].owner].push_back((int)units[i].d.out);
+    }
     // temporaries of the XORs: two parity banks (a step's ANDs write one bank while the previous step's ORs read the other)
     std::vector<uint32_t> xor_at(D + 2, 0);
     uint32_t max_x = 0;
-    for (const auto& u : units) if (u.lat == 2) max_x = std::max(max_x, ++xor_at[u.start]);
+    for (const auto& u : units) if (u.lat == 2 && (!sharded || u.owner == rank_)) max_x = std::max(max_x, ++xor_at[u.start]);
+    if (sharded) {   // the slot stride must be the same on every rank: size the banks for the fullest step of ANY rank
+        std::vector<uint32_t> cnt((size_t)(D + 2) * world_, 0);
+        for (const auto& u : units) if (u.lat == 2) max_x = std::max(max_x, ++cnt[(size_t)u.start * world_ + u.owner]);
+    }
     const uint32_t tmp0 = (uint32_t)W;
     relevel_stride_ = tmp0 + 4 * max_x;
     relevel_plan_.assign(D, RStep{});
     std::fill(xor_at.begin(), xor_at.end(), 0);
     for (const auto& u : units) {
+        if (sharded && u.owner != rank_) continue;
         if (u.lat == 1) {
             relevel_plan_[u.start - 1].descs.push_back(u.d);
         } else {
@@ -822,8 +882,18 @@ bool Circuit::checkRelevelPlan(std::string* why) const {
             if (written[d.out] == (int32_t)s) return fail("slot written twice in one step");
             written[d.out] = (int32_t)s;
         }
+        // gate sharding: what the other ranks publish after this step arrives before the next one
+        if (s < relevel_xw_.size())
+            for (uint32_t r = 0; r < world_; ++r) {
+                if (r == rank_) {
+                    for (int w : relevel_xw_[s][r]) if (written[w] != (int32_t)s) return fail("publishes register " + std::to_string(w) + " in a step that did not write it");
+                } else {
+                    for (int w : relevel_xw_[s][r]) { if (written[w] >= 0) return fail("receives a register it wrote itself"); written[w] = (int32_t)s; }
+                }
+            }
     }
-    for (size_t w = 0; w < W; ++w) if (is_out[w] && written[w] < 0) return fail("register " + std::to_string(w) + " never written");
+    if (relevel_xw_.empty())
+        for (size_t w = 0; w < W; ++w) if (is_out[w] && written[w] < 0) return fail("register " + std::to_string(w) + " never written");
     return true;
 }
 
@@ -839,7 +909,6 @@ void Circuit::setBalance(bool on, uint32_t lone, uint32_t full) {
 }
 
 void Circuit::clockReleveled() {
-    if (world_ > 1 && shard_mode_ == 1) throw std::logic_error("re-levelled schedule is not available with gate sharding");
     if (verify_flag) throw std::logic_error("re-levelled schedule is not available in verify mode");
     unsigned lo, hi;
     instanceRange(lo, hi);
@@ -853,7 +922,11 @@ void Circuit::clockReleveled() {
         ck(bce_eval_gates_strided(cc, (uint32_t)d.size(), d.data(), K, stride_), "Clock(re-levelled step)");
         ++stats_.sublaunches;
     };
-    for (const auto& st : relevel_plan_) launch(st.descs);
+    const bool sharded = world_ > 1 && shard_mode_ == 1;
+    for (size_t s = 0; s < relevel_plan_.size(); ++s) {
+        launch(relevel_plan_[s].descs);
+        if (sharded) exchangeWires(relevel_xw_[s]);   // outputs of this step whose consumers sit on other ranks
+    }
     launch(relevel_nots_);
     // OUTPUT gates
     std::vector<uint32_t> oslots;

@@ -223,6 +223,8 @@ private:
     void managerRound(size_t level);
     void executeRound(size_t level);
     void exchangeLevel(size_t level);
+    void exchangeWires(const std::vector<std::vector<int>>& pub);
+    std::vector<std::vector<std::vector<int>>> relevel_xw_;  // [step][rank] -> wires that rank publishes after the step (gate sharding)
     void gatherOutputs();
     void requireEngine(const char* what) const;
     void ck(int rc, const char* what) const;

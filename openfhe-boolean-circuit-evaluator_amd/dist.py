@@ -36,6 +36,20 @@ class Exchange:
                              self.host_send.data_ptr(), self.host_recv.data_ptr(),
                              self.dev_send.data_ptr() if device is not None else None,
                              self.dev_recv.data_ptr() if device is not None else None, cap)
+        # the plan for this world exists now: it may publish more per step than the estimate above (slack filling widens
+        # steps up to world x the device's capacity) -- ask again and grow the buffers if needed
+        need = (max(circuit.exchange_capacity(self.world, shard_mode, encrypted), 64) + 63) // 64 * 64
+        if need > cap:
+            self.cap = cap = need
+            self.host_send = torch.zeros(cap, dtype=torch.uint8)
+            self.host_recv = torch.zeros(cap * self.world, dtype=torch.uint8)
+            if device is not None:
+                self.dev_send = torch.zeros(cap, dtype=torch.uint8, device=device)
+                self.dev_recv = torch.zeros(cap * self.world, dtype=torch.uint8, device=device)
+            circuit.set_exchange(self.rank, self.world, shard_mode, self._allgather,
+                                 self.host_send.data_ptr(), self.host_recv.data_ptr(),
+                                 self.dev_send.data_ptr() if device is not None else None,
+                                 self.dev_recv.data_ptr() if device is not None else None, cap)
         if in_library and device is not None and encrypted:
             self._setup_in_library(circuit)
 

@@ -406,3 +406,34 @@ def test_balanced_bootstrap_depth_schedule_is_valid_and_cheaper(bce, name, new_f
     c.check_relevel()
     assert c.relevel_steps() == asap or sum(c.relevel_steps()) == sum(asap)
     c.close()
+
+
+@pytest.mark.parametrize("name,new_flag,K,world", [("AES-expanded.txt", False, 4, 2), ("AES-expanded.txt", False, 32, 8),
+                                                    ("sha256_new.txt", True, 16, 8), ("adder_64bit.txt", False, 3, 3),
+                                                    ("md5.txt", False, 1, 4)])
+def test_gate_sharded_bootstrap_depth_plans_are_consistent(bce, name, new_flag, K, world):
+    """Gate sharding on the bootstrap-depth schedule: every rank builds the same plan and keeps its own share of each step.
+    Host-side check over all ranks of a world (no GPU, no process group -- the plans are static): each rank's plan passes the
+    self-check with the other ranks' publications counted as arrivals (bce_circuit_check_relevel), the ranks' shares add
+    up to the single-rank schedule step by step, and no step leaves a rank more than one unit above its fair share."""
+    single = bce.Circuit()
+    single.ReadBristol(os.path.join(CIRCUITS, name), new_flag=new_flag)
+    single.setInstances(K)
+    single.setBalance(True, 256 * world, 512 * world)       # what world devices offer to one step
+    ref = single.relevel_steps()
+    single.close()
+    per_rank = []
+    for rank in range(world):
+        c = bce.Circuit()
+        c.ReadBristol(os.path.join(CIRCUITS, name), new_flag=new_flag)
+        c.setInstances(K)
+        c.setBalance(True, 256, 512)
+        c.set_exchange(rank, world, 1, lambda nbytes, on_dev: 0, None, None, None, None, 0)
+        c.check_relevel()
+        per_rank.append(c.relevel_steps())
+        c.close()
+    assert all(len(p) == len(ref) for p in per_rank)
+    for s in range(len(ref)):
+        shares = [p[s] for p in per_rank]
+        assert sum(shares) == ref[s], (s, shares, ref[s])
+        assert max(shares) <= (ref[s] + world - 1) // world + 3, (s, shares)   # contiguous split by weight; an XOR weighs up to 3

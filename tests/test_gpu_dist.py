@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, shard_mode, K, q):
+def _worker(rank, world, port, shard_mode, K, q, relevel=False):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -34,6 +34,9 @@ def _worker(rank, world, port, shard_mode, K, q):
         cases = [kat.adder_case(t, 32) for t in range(K)]
         c.Reset()
         c.setEncrypted(True)
+        if relevel:
+            c.setRelevel(True)
+            c.check_relevel()
         for k, (ins, _) in enumerate(cases):
             c.SetInput(ins, instance=k)
         c.Clock()
@@ -46,11 +49,11 @@ def _worker(rank, world, port, shard_mode, K, q):
         q.put((rank, False, repr(e), 0, 0))
 
 
-def _run(shard_mode, K, world=2):
+def _run(shard_mode, K, world=2, relevel=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000) + shard_mode
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shard_mode, K, q)) for r in range(world)]
+    port = 29700 + (os.getpid() % 1000) + shard_mode + (7 if relevel else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shard_mode, K, q, relevel)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -77,6 +80,18 @@ def test_encrypted_gate_sharding_exchanges_boundary_ciphertexts():
         assert exchanges > 0 and cts > 0
         total += boots
     assert total == 310                              # every bootstrap ran on exactly one rank
+
+
+def test_encrypted_gate_sharding_on_the_bootstrap_depth_schedule():
+    """gate sharding on the slack-filled bootstrap-depth schedule: every step's units are split over the ranks, the
+    outputs whose consumers sit on the other rank are exchanged after the step; same sums, every bootstrap on one rank"""
+    res = _run(1, K=2, relevel=True)
+    total = 0
+    for rank, ok, boots, exchanges, cts in res:
+        assert ok is True, res
+        assert exchanges > 0 and cts > 0
+        total += boots
+    assert total == 310 * 2
 
 
 def test_in_library_rccl_allgather_world_of_one():
