@@ -100,6 +100,9 @@ int bce_circuit_set_balance(bce_circuit*, int on, uint32_t lone, uint32_t full);
 /* Bootstraps per step of the current bootstrap-depth schedule, for ONE instance: writes min(*n_steps, cap) entries and
  * sets *n_steps to the number of steps. */
 int bce_circuit_relevel_steps(const bce_circuit*, uint32_t* sizes, uint32_t cap, uint32_t* n_steps);
+/* Gate sharding on that schedule: registers THIS rank publishes after each step (one allgather per step, padded to the
+ * widest rank).  Same calling convention as bce_circuit_relevel_steps; all zero without gate sharding. */
+int bce_circuit_relevel_publications(const bce_circuit*, uint32_t* counts, uint32_t cap, uint32_t* n_steps);
 /* Self-check of that schedule: every step reads only registers written by earlier steps (or inputs / constants), every XOR
  * temporary is consumed exactly one step after it is produced, every gate output is written once.  BCE_OK or
  * BCE_ERR_STATE with the finding in bce_circuit_last_error. */

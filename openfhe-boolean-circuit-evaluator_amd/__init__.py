@@ -355,7 +355,7 @@ CIRCUIT_SYMBOLS = [
     "bce_circuit_create", "bce_circuit_destroy", "bce_circuit_last_error", "bce_circuit_read_file",
     "bce_circuit_read_bristol", "bce_circuit_get_info", "bce_circuit_reset", "bce_circuit_rearm", "bce_circuit_set_plaintext",
     "bce_circuit_set_encrypted", "bce_circuit_set_verify", "bce_circuit_get_flags", "bce_circuit_set_batched",
-    "bce_circuit_set_encrypt_mode", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_balance", "bce_circuit_relevel_steps", "bce_circuit_check_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
+    "bce_circuit_set_encrypt_mode", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_balance", "bce_circuit_relevel_steps", "bce_circuit_relevel_publications", "bce_circuit_check_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
     "bce_circuit_get_output", "bce_circuit_get_buses", "bce_circuit_get_counts", "bce_circuit_get_stats", "bce_circuit_dump",
     "bce_circuit_set_exchange", "bce_circuit_enable_rccl", "bce_circuit_exchange_capacity", "bce_assemble_bristol", "bce_pool_gather",
     "bce_pool_scatter",
@@ -386,6 +386,7 @@ def _bind_circuit():
     L.bce_circuit_set_instances.argtypes = [vp, u32]
     L.bce_circuit_set_balance.argtypes = [vp, i32, u32, u32]
     L.bce_circuit_relevel_steps.argtypes = [vp, C.POINTER(u32), u32, C.POINTER(u32)]
+    L.bce_circuit_relevel_publications.argtypes = [vp, C.POINTER(u32), u32, C.POINTER(u32)]
     L.bce_circuit_check_relevel.argtypes = [vp]
     L.bce_circuit_set_input.argtypes = [vp, u32, vp, u32, vp]
     L.bce_circuit_get_output.argtypes = [vp, u32, vp]
@@ -539,6 +540,14 @@ class Circuit:
         self._ck(self._L.bce_circuit_relevel_steps(self.h, None, 0, C.byref(n)))
         buf = (C.c_uint32 * max(1, n.value))()
         self._ck(self._L.bce_circuit_relevel_steps(self.h, buf, n.value, C.byref(n)))
+        return [int(buf[i]) for i in range(n.value)]
+
+    def relevel_publications(self):
+        """registers this rank publishes after each step of the bootstrap-depth schedule (gate sharding)"""
+        n = C.c_uint32(0)
+        self._ck(self._L.bce_circuit_relevel_publications(self.h, None, 0, C.byref(n)))
+        buf = (C.c_uint32 * max(1, n.value))()
+        self._ck(self._L.bce_circuit_relevel_publications(self.h, buf, n.value, C.byref(n)))
         return [int(buf[i]) for i in range(n.value)]
 
     def check_relevel(self):

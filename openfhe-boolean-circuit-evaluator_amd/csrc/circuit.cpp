@@ -859,6 +859,12 @@ std::vector<uint32_t> Circuit::relevelStepSizes() const {
     return v;
 }
 
+std::vector<uint32_t> Circuit::relevelPublications() const {
+    std::vector<uint32_t> v(relevel_plan_.size(), 0);
+    for (size_t s = 0; s < relevel_xw_.size() && s < v.size(); ++s) v[s] = (uint32_t)relevel_xw_[s][rank_].size();
+    return v;
+}
+
 bool Circuit::checkRelevelPlan(std::string* why) const {
     const size_t W = wire_names_.size();
     std::vector<int32_t> written(relevel_stride_, -1);   // step that wrote a slot; inputs and constants: step -1 = "before"

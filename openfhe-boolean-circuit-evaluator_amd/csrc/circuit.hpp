@@ -129,6 +129,7 @@ public:
     void setBalance(bool on, uint32_t lone = 0, uint32_t full = 0);
     bool getBalance() const { return balance_; }
     std::vector<uint32_t> relevelStepSizes() const;          // bootstraps per step, one instance
+    std::vector<uint32_t> relevelPublications() const;       // registers this rank publishes per step (gate sharding)
     bool checkRelevelPlan(std::string* why = nullptr) const; // every step reads only what earlier steps wrote
     bool getXorFast() const { return xor_fast_; }
     void setQuiet(bool q) { quiet_ = q; }

@@ -90,6 +90,13 @@ int bce_circuit_relevel_steps(const bce_circuit* h, uint32_t* sizes, uint32_t ca
     *n_steps = (uint32_t)v.size();
     return BCE_OK;
 }
+int bce_circuit_relevel_publications(const bce_circuit* h, uint32_t* counts, uint32_t cap, uint32_t* n_steps) {
+    if (!h || !n_steps || (cap && !counts)) return BCE_ERR_ARG;
+    const std::vector<uint32_t> v = h->c.relevelPublications();
+    for (size_t i = 0; i < v.size() && i < cap; ++i) counts[i] = v[i];
+    *n_steps = (uint32_t)v.size();
+    return BCE_OK;
+}
 int bce_circuit_check_relevel(bce_circuit* h) {
     return guarded(h, [&] {
         std::string why;
