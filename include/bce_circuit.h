@@ -107,6 +107,14 @@ int bce_circuit_relevel_publications(const bce_circuit*, uint32_t* counts, uint3
  * temporary is consumed exactly one step after it is produced, every gate output is written once.  BCE_OK or
  * BCE_ERR_STATE with the finding in bce_circuit_last_error. */
 int bce_circuit_check_relevel(bce_circuit*);
+/* opt-in extension: the DATAFLOW schedule -- the whole bootstrap DAG goes to the engine as one bce_dag (bce_gpu.h)
+ * and one Clock() is ONE persistent kernel launch in which a finished bootstrap releases its consumers on the device:
+ * the ready-gate rule of Circuit::_ManageGates (src/circuit.cpp:575-683) applied per gate, not per frontier, with no
+ * kernel boundary between dependent gates.  Same ciphertexts in every register.  XOR temporaries get slots of their
+ * own, so call it before SetInput.  Ignored (the bootstrap-depth schedule runs instead) in verify mode, under gate
+ * sharding and for parameter classes without the persistent kernel: bce_circuit_dataflow_active tells. */
+int bce_circuit_set_dataflow(bce_circuit*, int on);
+int bce_circuit_dataflow_active(const bce_circuit*);   /* 1 if the next encrypted Clock() takes the dataflow path */
 /* K independent input sets evaluated in lock-step (call before SetInput) */
 int bce_circuit_set_instances(bce_circuit*, uint32_t k);
 /* Circuit::SetInput, src/circuit.cpp:455-530: bits = concatenation of the input buses,

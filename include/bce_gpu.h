@@ -69,7 +69,8 @@ enum bce_br_kernel {
     BCE_BR_SPLIT_X1 = 1,           /* k_blind_rotate_lat<4,2>: split inverse transform, launches of <= #CU workgroups */
     BCE_BR_SPLIT_X2 = 2,           /* k_blind_rotate_lat<4,4>: same, register budget for two workgroups per CU */
     BCE_BR_WORD64 = 3,             /* k_blind_rotate64: ring modulus >= 2^28 */
-    BCE_BR_KERNELS = 4
+    BCE_BR_DAG = 4,                /* k_bootstrap_dag: one persistent launch per bce_dag_run (tail fused) */
+    BCE_BR_KERNELS = 5
 };
 
 /* cumulative device timing, measured with HIP events on the engine's stream */
@@ -165,6 +166,37 @@ int bce_eval_gates(bce_ctx*, uint32_t n_desc, const bce_gate_desc* descs);
 int bce_eval_gates_strided(bce_ctx*, uint32_t n_desc, const bce_gate_desc* descs, uint32_t instances,
                            uint32_t slot_stride);
 int bce_synchronize(bce_ctx*);
+
+/* ---- the hot path, dependency-driven ------------------------------------------------------------------
+ * The reference alternates Circuit::_ManageGates (a gate is ready when every input wire has arrived,
+ * src/circuit.cpp:575-683) with Circuit::_ExecuteGates (src/circuit.cpp:685-817) once per frontier.  A bce_dag
+ * hands the engine the WHOLE bootstrap DAG of a circuit instead: `tasks` are bootstrapped gates in topological
+ * order, in SSA form (every `out` slot is written by exactly one task and only read by later ones; inputs no
+ * task writes are primary inputs).  bce_dag_run evaluates `instances` input sets `slot_stride` slots apart in ONE
+ * persistent kernel launch: dependency counters and ready queues live in device memory, a workgroup that finishes a
+ * bootstrap releases its consumers, idle workgroups pull the next ready bootstrap -- no kernel boundary and no
+ * device-wide barrier between dependent gates.  Every register holds the same ciphertext as under
+ * bce_eval_gates_strided called frontier by frontier.  `prio` (may be NULL) gives each task a priority class
+ * 0 (most urgent) .. 3; ready tasks of a lower class number are pulled first.
+ * Asynchronous like bce_eval_gates; a run in which the device scheduler made no progress for the stall limit
+ * (bce_dag_set_limits) abandons its queues and the next synchronising call returns BCE_ERR_STATE. */
+typedef struct bce_dag bce_dag;
+int bce_dag_supported(const bce_ctx*);   /* 1 when this context's parameter class has the persistent kernel */
+int bce_dag_create(bce_ctx*, uint32_t n_tasks, const bce_gate_desc* tasks, const uint8_t* prio, bce_dag** out);
+/* instance k of a run uses the DAG's slot numbers shifted by slot_base + k * slot_stride */
+int bce_dag_run(bce_ctx*, bce_dag*, uint32_t instances, uint32_t slot_stride, uint32_t slot_base);
+void bce_dag_destroy(bce_ctx*, bce_dag*);
+/* workgroups_per_cu: 0 = choose by the work per dependency level, 1 or 2 = force; placement: 1 = idle compute
+ * units claim ready bootstraps first (default), 0 = first poller wins; lazy_us: how long a half-busy compute unit
+ * leaves a short queue to idle ones; stall_ms: no completion anywhere for this long abandons the run. */
+int bce_dag_set_limits(bce_ctx*, int workgroups_per_cu, int placement, uint32_t lazy_us, uint32_t stall_ms);
+/* counters of the last finished bce_dag_run (after a synchronising call): out[0] bootstraps completed,
+ * out[1] claims a half-busy compute unit delayed in favour of an idle one, out[2] abort code (0 = none),
+ * out[3] workgroups per CU the run used */
+int bce_dag_last_run(bce_ctx*, uint64_t out[4]);
+/* test hook: task `t` of the DAG waits for one producer more than it has, so it never becomes ready and the run
+ * stalls (exercises the bounded-spin exit) */
+int bce_dag_debug_block_task(bce_dag*, uint32_t t);
 
 /* ---- measurement ------------------------------------------------------- */
 int bce_timing_reset(bce_ctx*);

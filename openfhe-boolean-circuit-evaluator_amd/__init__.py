@@ -42,13 +42,15 @@ class GateDesc(C.Structure):
 
 
 BR_KERNEL_NAMES = ["k_blind_rotate (one wave per transform)", "k_blind_rotate_lat<4,2> (split transform, 1 workgroup/CU)",
-                   "k_blind_rotate_lat<4,4> (split transform, 2 workgroups/CU)", "k_blind_rotate64 (64-bit modulus)"]
+                   "k_blind_rotate_lat<4,4> (split transform, 2 workgroups/CU)", "k_blind_rotate64 (64-bit modulus)",
+                   "k_bootstrap_dag (persistent, dependency-driven, tail fused)"]
+BR_KERNELS = len(BR_KERNEL_NAMES)
 
 
 class Timing(C.Structure):
     _fields_ = [("blind_rotate_ms", C.c_double), ("tail_ms", C.c_double),
                 ("blind_rotate_launches", C.c_uint64), ("bootstraps", C.c_uint64),
-                ("br_ms", C.c_double * 4), ("br_launches", C.c_uint64 * 4), ("br_bootstraps", C.c_uint64 * 4),
+                ("br_ms", C.c_double * BR_KERNELS), ("br_launches", C.c_uint64 * BR_KERNELS), ("br_bootstraps", C.c_uint64 * BR_KERNELS),
                 ("fused_tail_launches", C.c_uint64)]
 
 
@@ -59,6 +61,7 @@ ENGINE_SYMBOLS = [
     "bce_encrypt_bits", "bce_set_encrypt_seed", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize",
     "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_forward_transforms_per_step", "bce_launch_capacity", "bce_rccl_available", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
     "bce_rccl_shutdown", "bce_debug_eval_stages", "bce_debug_ntt",
+    "bce_dag_supported", "bce_dag_create", "bce_dag_run", "bce_dag_destroy", "bce_dag_set_limits", "bce_dag_last_run", "bce_dag_debug_block_task",
 ]
 
 _lib = None
@@ -122,6 +125,14 @@ def lib():
     L.bce_rccl_shutdown.argtypes = [vp]
     L.bce_debug_eval_stages.argtypes = [vp, u32, vp, vp, vp, vp]
     L.bce_debug_ntt.argtypes = [vp, vp, u32, i32]
+    L.bce_dag_supported.argtypes = [vp]
+    L.bce_dag_create.argtypes = [vp, u32, vp, vp, C.POINTER(vp)]
+    L.bce_dag_run.argtypes = [vp, vp, u32, u32, u32]
+    L.bce_dag_destroy.argtypes = [vp, vp]
+    L.bce_dag_destroy.restype = None
+    L.bce_dag_set_limits.argtypes = [vp, i32, i32, u32, u32]
+    L.bce_dag_last_run.argtypes = [vp, C.POINTER(u64)]
+    L.bce_dag_debug_block_task.argtypes = [vp, u32]
     _lib = L
     return L
 
@@ -278,10 +289,43 @@ class BinFHEContext:
                 "blind_rotate_launches": int(t.blind_rotate_launches), "bootstraps": int(t.bootstraps),
                 "fused_tail_launches": int(t.fused_tail_launches),
                 "by_kernel": [{"kernel": BR_KERNEL_NAMES[k], "ms": t.br_ms[k], "launches": int(t.br_launches[k]),
-                               "bootstraps": int(t.br_bootstraps[k])} for k in range(4)]}
+                               "bootstraps": int(t.br_bootstraps[k])} for k in range(BR_KERNELS)]}
 
     def bytes_per_bootstrap(self):
         return int(self._L.bce_bytes_per_bootstrap(self.h))
+
+    # --- dependency-driven evaluation: the whole bootstrap DAG in one persistent launch (bce_dag_*) ---
+    def dag_supported(self):
+        return bool(self._L.bce_dag_supported(self.h))
+
+    def dag_create(self, tasks, prio=None):
+        """tasks: (op, in0, in1, out[, neg0, neg1]) in topological order, SSA slots; returns an opaque handle"""
+        arr = (GateDesc * len(tasks))()
+        for i, t in enumerate(tasks):
+            arr[i] = GateDesc(*(tuple(t) + (0, 0))[:6])
+        pr = None
+        if prio is not None:
+            pr = (C.c_uint8 * len(tasks))(*[int(x) for x in prio])
+        h = C.c_void_p()
+        self._ck(self._L.bce_dag_create(self.h, len(tasks), arr, pr, C.byref(h)))
+        return h
+
+    def dag_run(self, dag, instances=1, slot_stride=0, slot_base=0):
+        self._ck(self._L.bce_dag_run(self.h, dag, int(instances), int(slot_stride), int(slot_base)))
+
+    def dag_destroy(self, dag):
+        self._L.bce_dag_destroy(self.h, dag)
+
+    def dag_set_limits(self, workgroups_per_cu=0, placement=1, lazy_us=20, stall_ms=4000):
+        self._ck(self._L.bce_dag_set_limits(self.h, int(workgroups_per_cu), int(placement), int(lazy_us), int(stall_ms)))
+
+    def dag_last_run(self):
+        out = (C.c_uint64 * 4)()
+        self._ck(self._L.bce_dag_last_run(self.h, out))
+        return {"done": int(out[0]), "lazy_waits": int(out[1]), "abort": int(out[2]), "workgroups_per_cu": int(out[3])}
+
+    def dag_debug_block_task(self, dag, t):
+        self._ck(self._L.bce_dag_debug_block_task(dag, int(t)))
 
     # --- in-library RCCL all-gather on the engine stream (multi-GPU exchange without host sync) ---
     @staticmethod
@@ -355,7 +399,7 @@ CIRCUIT_SYMBOLS = [
     "bce_circuit_create", "bce_circuit_destroy", "bce_circuit_last_error", "bce_circuit_read_file",
     "bce_circuit_read_bristol", "bce_circuit_get_info", "bce_circuit_reset", "bce_circuit_rearm", "bce_circuit_set_plaintext",
     "bce_circuit_set_encrypted", "bce_circuit_set_verify", "bce_circuit_get_flags", "bce_circuit_set_batched",
-    "bce_circuit_set_encrypt_mode", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_balance", "bce_circuit_relevel_steps", "bce_circuit_relevel_publications", "bce_circuit_check_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
+    "bce_circuit_set_encrypt_mode", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_dataflow", "bce_circuit_dataflow_active", "bce_circuit_set_balance", "bce_circuit_relevel_steps", "bce_circuit_relevel_publications", "bce_circuit_check_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
     "bce_circuit_get_output", "bce_circuit_get_buses", "bce_circuit_get_counts", "bce_circuit_get_stats", "bce_circuit_dump",
     "bce_circuit_set_exchange", "bce_circuit_enable_rccl", "bce_circuit_exchange_capacity", "bce_assemble_bristol", "bce_pool_gather",
     "bce_pool_scatter",
@@ -385,6 +429,8 @@ def _bind_circuit():
     L.bce_circuit_get_flags.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.bce_circuit_set_instances.argtypes = [vp, u32]
     L.bce_circuit_set_balance.argtypes = [vp, i32, u32, u32]
+    L.bce_circuit_set_dataflow.argtypes = [vp, i32]
+    L.bce_circuit_dataflow_active.argtypes = [vp]
     L.bce_circuit_relevel_steps.argtypes = [vp, C.POINTER(u32), u32, C.POINTER(u32)]
     L.bce_circuit_relevel_publications.argtypes = [vp, C.POINTER(u32), u32, C.POINTER(u32)]
     L.bce_circuit_check_relevel.argtypes = [vp]
@@ -526,6 +572,13 @@ class Circuit:
     def setRelevel(self, b):
         """opt-in: bootstrap-depth schedule (fewer dependent launches, same ciphertexts)"""
         self._ck(self._L.bce_circuit_set_relevel(self.h, int(b)))
+
+    def setDataflow(self, b):
+        """opt-in: the whole bootstrap DAG in one persistent launch (device-side ready-gate rule); before SetInput"""
+        self._ck(self._L.bce_circuit_set_dataflow(self.h, int(b)))
+
+    def dataflowActive(self):
+        return bool(self._L.bce_circuit_dataflow_active(self.h))
 
     def setInstances(self, k):
         self._ck(self._L.bce_circuit_set_instances(self.h, int(k)))

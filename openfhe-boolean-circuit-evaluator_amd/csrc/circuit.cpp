@@ -174,6 +174,7 @@ Circuit::Circuit(bce_ctx* engine) : cc(engine) {
 }
 
 Circuit::~Circuit() {
+    dropDag();
     if (owns_engine_ && cc) bce_ctx_destroy(cc);
 }
 
@@ -644,16 +645,16 @@ void Circuit::launchCapacity(uint32_t& lone, uint32_t& full) const {
     }
 }
 
-void Circuit::buildRelevelPlan() {
+// units of the bootstrap DAG in topological order (NOT chains resolved into negation flags); returns the bootstrap depth
+uint32_t Circuit::buildUnits(std::vector<Unit>& units, std::vector<int>& base, std::vector<uint8_t>& neg) const {
     const size_t W = wire_names_.size(), G = allGates.size();
     // resolve NOT chains: wire -> (base wire, negated)
-    std::vector<int> base(W);
-    std::vector<uint8_t> neg(W, 0);
+    base.resize(W);
+    neg.assign(W, 0);
     for (size_t w = 0; w < W; ++w) base[w] = (int)w;
     // gates are in topological (file) order per level; walk levels so that bases are resolved first
     std::vector<uint32_t> depth(W, 0);
-    struct Unit { uint32_t asap, start; uint8_t lat, owner; bce_gate_desc d; int32_t p0, p1; };   // XOR: d holds (in0, in1, out, n0, n1)
-    std::vector<Unit> units;
+    units.clear();
     std::vector<int32_t> prod(W, -1);   // base wire -> unit that produces it
     units.reserve(G);
     for (const auto& L : levels_)
@@ -682,9 +683,42 @@ void Circuit::buildRelevelPlan() {
                 units.push_back(u);
             }
         }
-    const size_t U = units.size();
     uint32_t D = 0;
     for (const auto& u : units) D = std::max(D, u.asap + u.lat - 1);
+    return D;
+}
+
+// successors (CSR) and ALAP start steps of the units (which are in topological order)
+void Circuit::unitSuccessorsAlap(const std::vector<Unit>& units, uint32_t D, std::vector<uint32_t>& soff, std::vector<uint32_t>& succ,
+                                 std::vector<uint32_t>& alap) {
+    const size_t U = units.size();
+    soff.assign(U + 1, 0);
+    for (const auto& u : units) { if (u.p0 >= 0) ++soff[u.p0 + 1]; if (u.p1 >= 0 && u.p1 != u.p0) ++soff[u.p1 + 1]; }
+    for (size_t i = 0; i < U; ++i) soff[i + 1] += soff[i];
+    succ.resize(soff[U]);
+    {
+        std::vector<uint32_t> fill(soff.begin(), soff.end() - 1);
+        for (size_t i = 0; i < U; ++i) {
+            const Unit& u = units[i];
+            if (u.p0 >= 0) succ[fill[u.p0]++] = (uint32_t)i;
+            if (u.p1 >= 0 && u.p1 != u.p0) succ[fill[u.p1]++] = (uint32_t)i;
+        }
+    }
+    alap.resize(U);
+    for (size_t i = U; i-- > 0;) {
+        uint32_t a = D - units[i].lat + 1;
+        for (uint32_t k = soff[i]; k < soff[i + 1]; ++k) a = std::min(a, alap[succ[k]] - units[i].lat);
+        alap[i] = a;
+    }
+}
+
+void Circuit::buildRelevelPlan() {
+    const size_t W = wire_names_.size();
+    std::vector<int> base;
+    std::vector<uint8_t> neg;
+    std::vector<Unit> units;
+    const uint32_t D = buildUnits(units, base, neg);
+    const size_t U = units.size();
     unsigned ilo, ihi;
     instanceRange(ilo, ihi);
     const uint64_t K = std::max(1u, ihi - ilo);
@@ -693,25 +727,8 @@ void Circuit::buildRelevelPlan() {
         uint32_t lone, full;
         launchCapacity(lone, full);
         if (sharded) { lone *= world_; full *= world_; }   // the stairs of world_ devices working on one step
-        // successors (CSR) and ALAP start steps (units are in topological order)
-        std::vector<uint32_t> soff(U + 1, 0), succ;
-        for (const auto& u : units) { if (u.p0 >= 0) ++soff[u.p0 + 1]; if (u.p1 >= 0 && u.p1 != u.p0) ++soff[u.p1 + 1]; }
-        for (size_t i = 0; i < U; ++i) soff[i + 1] += soff[i];
-        succ.resize(soff[U]);
-        {
-            std::vector<uint32_t> fill(soff.begin(), soff.end() - 1);
-            for (size_t i = 0; i < U; ++i) {
-                const Unit& u = units[i];
-                if (u.p0 >= 0) succ[fill[u.p0]++] = (uint32_t)i;
-                if (u.p1 >= 0 && u.p1 != u.p0) succ[fill[u.p1]++] = (uint32_t)i;
-            }
-        }
-        std::vector<uint32_t> alap(U);
-        for (size_t i = U; i-- > 0;) {
-            uint32_t a = D - units[i].lat + 1;
-            for (uint32_t k = soff[i]; k < soff[i + 1]; ++k) a = std::min(a, alap[succ[k]] - units[i].lat);
-            alap[i] = a;
-        }
+        std::vector<uint32_t> soff, succ, alap;
+        unitSuccessorsAlap(units, D, soff, succ, alap);
         // list scheduling, least slack first
         using Key = std::pair<uint32_t, uint32_t>;   // (ALAP step, unit)
         std::priority_queue<Key, std::vector<Key>, std::greater<Key>> ready;
@@ -838,7 +855,9 @@ void Circuit::buildRelevelPlan() {
 // The stride is part of the pool layout: not after SetInput.
 void Circuit::rebuildRelevel() {
     buildRelevelPlan();
+    if (dataflow_) buildDagTasks();
     uint32_t need = std::max(base_stride_, relevel_stride_);
+    if (dataflow_) need = std::max(need, dag_stride_);
     if (inputs_set_ && need > stride_ && balance_) {
         // the inputs already sit in a pool laid out for a smaller stride: keep the layout, fall back to ASAP placement
         // (whose temporaries the stride of finalizeNetlist() always covers)
@@ -846,6 +865,7 @@ void Circuit::rebuildRelevel() {
         buildRelevelPlan();
         balance_ = true;
         need = std::max(base_stride_, relevel_stride_);
+        if (dataflow_) need = std::max(need, dag_stride_);
     }
     if (inputs_set_ && need > stride_) throw std::logic_error("the schedule needs a larger slot stride than the pool was laid out with");
     if (!inputs_set_) stride_ = need;
@@ -933,7 +953,83 @@ void Circuit::clockReleveled() {
         launch(relevel_plan_[s].descs);
         if (sharded) exchangeWires(relevel_xw_[s]);   // outputs of this step whose consumers sit on other ranks
     }
-    launch(relevel_nots_);
+    finishReleveled(lo, hi);
+    stats_.levels = (uint32_t)relevel_plan_.size();
+}
+
+// ---- dataflow schedule: the whole bootstrap DAG in one persistent launch (bce_dag_*) -------------------------------
+// Tasks = the units of the bootstrap-depth schedule in topological order, an XOR as its two ANDs and its OR with
+// temporaries of its own (SSA: the device runs independent tasks in any order, so no slot may be reused).  Priority
+// class of a task = slack of its unit (ALAP step - ASAP step): the device pulls ready tasks of the critical path first.
+void Circuit::buildDagTasks() {
+    const size_t W = wire_names_.size();
+    std::vector<int> base;
+    std::vector<uint8_t> neg;
+    std::vector<Unit> units;
+    const uint32_t D = buildUnits(units, base, neg);
+    std::vector<uint32_t> soff, succ, alap;
+    unitSuccessorsAlap(units, D, soff, succ, alap);
+    uint32_t cls[3] = {0, 2, 8};   // slack bounds of classes 0, 1, 2 (steps); development knob BCE_DAG_CLASSES=a,b,c
+    if (const char* e = std::getenv("BCE_DAG_CLASSES")) std::sscanf(e, "%u,%u,%u", &cls[0], &cls[1], &cls[2]);
+    dag_tasks_.clear(); dag_prio_.clear();
+    uint32_t nx = 0;
+    for (size_t i = 0; i < units.size(); ++i) {
+        const Unit& u = units[i];
+        const uint32_t slack = alap[i] - u.asap;
+        const uint8_t pc = slack <= cls[0] ? 0 : slack <= cls[1] ? 1 : slack <= cls[2] ? 2 : 3;
+        if (u.lat == 1) {
+            dag_tasks_.push_back(u.d); dag_prio_.push_back(pc);
+        } else {
+            const uint32_t t1 = (uint32_t)W + 2 * nx, t2 = t1 + 1;
+            ++nx;
+            // (a AND !b), (!a AND b) with the inputs' own negations folded in, then their OR (src/gate.cpp:198-202)
+            dag_tasks_.push_back({BCE_AND, u.d.in0, u.d.in1, t1, u.d.neg0, u.d.neg1 ^ 1u});
+            dag_tasks_.push_back({BCE_AND, u.d.in0, u.d.in1, t2, u.d.neg0 ^ 1u, u.d.neg1});
+            dag_tasks_.push_back({BCE_OR, t1, t2, u.d.out, 0, 0});
+            dag_prio_.insert(dag_prio_.end(), 3, pc);
+        }
+    }
+    dag_stride_ = (uint32_t)W + 2 * nx;
+    dropDag();
+}
+
+void Circuit::dropDag() {
+    if (dag_) { bce_dag_destroy(cc, dag_); dag_ = nullptr; }
+}
+
+void Circuit::setDataflow(bool b) {
+    if (b && inputs_set_ && !dataflow_) throw std::logic_error("setDataflow: choose the dataflow schedule before SetInput (it lays the pool out with its own temporaries)");
+    dataflow_ = b;
+    rebuildRelevel();
+}
+
+bool Circuit::dataflowActive() const {
+    return dataflow_ && cc && !verify_flag && !(world_ > 1 && shard_mode_ == 1) && bce_dag_supported(cc) && !dag_tasks_.empty();
+}
+
+void Circuit::clockDataflow() {
+    unsigned lo, hi;
+    instanceRange(lo, hi);
+    if (dag_stride_ > stride_) throw std::logic_error("dataflow schedule needs more scratch slots than the pool stride");
+    if (relevel_plan_.empty()) rebuildRelevel();
+    if (!dag_) ck(bce_dag_create(cc, (uint32_t)dag_tasks_.size(), dag_tasks_.data(), dag_prio_.data(), &dag_), "Clock(dataflow DAG)");
+    if (hi > lo) {
+        ck(bce_dag_run(cc, dag_, hi - lo, stride_, lo * stride_), "Clock(dataflow run)");
+        ++stats_.sublaunches;
+    }
+    finishReleveled(lo, hi);
+    stats_.levels = 1;
+}
+
+// NOT wires the OUTPUT gates read, OUTPUT gates (decrypt), gate counts: common end of the two DAG-level schedules
+void Circuit::finishReleveled(unsigned lo, unsigned hi) {
+    const uint32_t K = hi - lo;
+    if (!relevel_nots_.empty() && K) {
+        std::vector<bce_gate_desc> d(relevel_nots_);
+        for (auto& e : d) { e.in0 += lo * stride_; e.in1 += lo * stride_; e.out += lo * stride_; }
+        ck(bce_eval_gates_strided(cc, (uint32_t)d.size(), d.data(), K, stride_), "Clock(output NOTs)");
+        ++stats_.sublaunches;
+    }
     // OUTPUT gates
     std::vector<uint32_t> oslots;
     std::vector<std::pair<unsigned, int>> obits;
@@ -955,7 +1051,6 @@ void Circuit::clockReleveled() {
             default: break;
         }
     }
-    stats_.levels = (uint32_t)relevel_plan_.size();
 }
 
 // ---- Clock -------------------------------------------------------------------------------------
@@ -1115,10 +1210,10 @@ Outputs Circuit::Clock() {
         boots0 = t.bootstraps;
     }
     size_t done_gates = 0;
-    const bool releveled = relevel_ && encrypted_flag && !plaintext_flag;
+    const bool releveled = (relevel_ || dataflow_) && encrypted_flag && !plaintext_flag;
     if (releveled) {
         auto t0 = Clock_t::now();
-        clockReleveled();
+        if (dataflowActive()) clockDataflow(); else clockReleveled();
         execution += ms_since(t0);
         done_gates = allGates.size();
     }

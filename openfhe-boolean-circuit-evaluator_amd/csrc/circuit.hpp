@@ -127,6 +127,16 @@ public:
     // the bootstrap-depth schedule fills its steps by slack up to the launch staircase of the engine (default on; see
     // buildRelevelPlan).  lone / full = 0: ask the engine (bce_launch_capacity), else use these capacities (tests).
     void setBalance(bool on, uint32_t lone = 0, uint32_t full = 0);
+    // opt-in: hand the engine the whole bootstrap DAG (bce_dag_*): ONE persistent launch per Clock() in which a finished
+    // bootstrap releases its consumers on the device -- the ready-gate rule of the reference's manager
+    // (src/circuit.cpp:575-683) applied per gate instead of per frontier.  Same ciphertexts in every register as the
+    // other schedules.  XOR temporaries get slots of their own (SSA), so it must be chosen before SetInput; it is
+    // ignored (the bootstrap-depth schedule runs) in verify mode, under gate sharding and for parameter classes
+    // without the persistent kernel.
+    void setDataflow(bool b);
+    bool getDataflow() const { return dataflow_; }
+    bool dataflowActive() const;
+    uint32_t dataflowTasks() const { return (uint32_t)dag_tasks_.size(); }
     bool getBalance() const { return balance_; }
     std::vector<uint32_t> relevelStepSizes() const;          // bootstraps per step, one instance
     std::vector<uint32_t> relevelPublications() const;       // registers this rank publishes per step (gate sharding)
@@ -218,6 +228,19 @@ private:
     bool balance_ = true;
     uint32_t cap_lone_ = 0, cap_full_ = 0;
     void launchCapacity(uint32_t& lone, uint32_t& full) const;
+    struct Unit { uint32_t asap, start; uint8_t lat, owner; bce_gate_desc d; int32_t p0, p1; };   // XOR (lat 2): d holds (in0, in1, out, n0, n1)
+    uint32_t buildUnits(std::vector<Unit>& units, std::vector<int>& base, std::vector<uint8_t>& neg) const;
+    static void unitSuccessorsAlap(const std::vector<Unit>& units, uint32_t D, std::vector<uint32_t>& soff, std::vector<uint32_t>& succ,
+                                   std::vector<uint32_t>& alap);
+    bool dataflow_ = false;
+    bce_dag* dag_ = nullptr;
+    std::vector<bce_gate_desc> dag_tasks_;
+    std::vector<uint8_t> dag_prio_;
+    uint32_t dag_stride_ = 0;
+    void buildDagTasks();
+    void dropDag();
+    void clockDataflow();
+    void finishReleveled(unsigned lo, unsigned hi);
     void buildRelevelPlan();
     void rebuildRelevel();
     void clockReleveled();

@@ -82,6 +82,8 @@ int bce_circuit_set_encrypt_mode(bce_circuit* h, int mode) {
 int bce_circuit_set_xor_fast(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setXorFast(on != 0); }); }
 int bce_circuit_set_relevel(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setRelevel(on != 0); }); }
 int bce_circuit_set_instances(bce_circuit* h, uint32_t k) { return guarded(h, [&] { h->c.setInstances(k); }); }
+int bce_circuit_set_dataflow(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setDataflow(on != 0); }); }
+int bce_circuit_dataflow_active(const bce_circuit* h) { return h && h->c.dataflowActive() ? 1 : 0; }
 int bce_circuit_set_balance(bce_circuit* h, int on, uint32_t lone, uint32_t full) { return guarded(h, [&] { h->c.setBalance(on != 0, lone, full); }); }
 int bce_circuit_relevel_steps(const bce_circuit* h, uint32_t* sizes, uint32_t cap, uint32_t* n_steps) {
     if (!h || !n_steps || (cap && !sizes)) return BCE_ERR_ARG;

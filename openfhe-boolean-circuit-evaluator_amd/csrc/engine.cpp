@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -115,6 +116,19 @@ struct bce_ctx {
     // timing
     std::vector<EventPair> pending, free_events;
     bce_timing timing{};
+    // dependency-driven runs (bce_dag_*): device copy of P, knobs, and the status words of runs not yet checked
+    DevParams* d_P = nullptr;
+    int dag_wg_per_cu = 0, dag_placement = 1;
+    uint32_t dag_lazy_us = 20, dag_stall_ms = 4000;
+    struct DagStatus { uint32_t abort, done, lazy_waits, pad; };
+    static constexpr int kDagRuns = 32;
+    DagStatus* h_dag_status = nullptr;        // pinned, kDagRuns entries
+    struct DagStage { DevParams P; DagParams D; };
+    DagStage* h_dag_stage = nullptr;          // pinned, kDagRuns entries: sources of the stream-ordered parameter uploads
+    uint64_t dag_expected[kDagRuns] = {0};
+    int dag_wps_used[kDagRuns] = {0};
+    int dag_pending = 0;
+    uint64_t dag_last[4] = {0, 0, 0, 0};
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -500,6 +514,25 @@ int keygen_bsk(bce_ctx* c, const KeygenParams& kp, KeygenDev& D) {
     return BCE_OK;
 }
 
+// after a stream synchronisation: verdict of the dependency-driven runs that finished since the last check
+int check_dag_runs(bce_ctx* c) {
+    int rc = BCE_OK;
+    for (int i = 0; i < c->dag_pending; ++i) {
+        const bce_ctx::DagStatus& st = c->h_dag_status[i];
+        c->dag_last[0] = st.done; c->dag_last[1] = st.lazy_waits; c->dag_last[2] = st.abort; c->dag_last[3] = (u64)c->dag_wps_used[i] / 2;
+        if (st.abort != 0 || st.done != c->dag_expected[i])
+            rc = c->fail(BCE_ERR_STATE, "bce_dag_run: the device scheduler gave up (abort code %u, %u of %llu bootstraps completed, no progress for %u ms)",
+                         st.abort, st.done, (unsigned long long)c->dag_expected[i], c->dag_stall_ms);
+    }
+    c->dag_pending = 0;
+    return rc;
+}
+
+int sync_stream(bce_ctx* c) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return check_dag_runs(c);
+}
+
 int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances, u32 slot_stride, u64* dbg_acc,
               u64* dbg_lweN, u64* dbg_ks) {
     if (n_desc == 0 || instances == 0) return BCE_OK;
@@ -626,6 +659,7 @@ void bce_ctx_destroy(bce_ctx* c) {
         if (c->h_descs[i]) hipHostFree(c->h_descs[i]);
         if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
     }
+    hipFree(c->d_P); if (c->h_dag_status) hipHostFree(c->h_dag_status); if (c->h_dag_stage) hipHostFree(c->h_dag_stage);
     hipFree(c->d_twf); hipFree(c->d_psi); hipFree(c->d_tw64); hipFree(c->d_tw64d); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc); hipFree(c->d_tail_partial);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -827,7 +861,7 @@ int bce_lwe_read(bce_ctx* c, const uint32_t* slots, uint32_t count, uint64_t* ct
     if (!c || !slots || !cts) return BCE_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t W = c->n + 1;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { const int rc = sync_stream(c); if (rc) return rc; }
     // one bulk copy when the request is dense enough, else per slot
     u32 lo = ~0u, hi = 0;
     for (u32 i = 0; i < count; ++i) {
@@ -937,7 +971,209 @@ int bce_eval_gates_strided(bce_ctx* c, uint32_t n_desc, const bce_gate_desc* des
 int bce_synchronize(bce_ctx* c) {
     if (!c) return BCE_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return sync_stream(c);
+}
+
+// ---- dependency-driven evaluation (include/bce_gpu.h, "the hot path, dependency-driven") --------------------------
+}  // extern "C" (the object below is C++)
+
+struct bce_dag {
+    u32 n_tasks = 0;
+    u32 max_slot = 0;
+    u32 qcount[kDagQueues] = {0, 0, 0, 0};        // tasks per priority class
+    u32 depth = 0;                                 // longest producer chain (bootstraps)
+    std::vector<u32> h_dep_init;
+    std::vector<u32> init_items;                   // initially ready tasks by class
+    u32 init_off[kDagQueues + 1] = {0, 0, 0, 0, 0};
+    // immutable device arrays
+    bce_gate_desc* d_tasks = nullptr;
+    u32 *d_cons_off = nullptr, *d_cons = nullptr, *d_dep_init = nullptr, *d_init = nullptr;
+    uint8_t* d_qid = nullptr;
+    // per-run state, grown on demand
+    u32* d_dep = nullptr; size_t dep_cap = 0;
+    u32* d_slots[kDagQueues] = {nullptr, nullptr, nullptr, nullptr}; size_t slots_cap[kDagQueues] = {0, 0, 0, 0};
+    u32* d_ctl = nullptr;
+    DagParams* d_params = nullptr;
+};
+
+extern "C" {
+
+int bce_dag_supported(const bce_ctx* c) { return c && dag_kernel_available(c->P) ? 1 : 0; }
+
+int bce_dag_set_limits(bce_ctx* c, int workgroups_per_cu, int placement, uint32_t lazy_us, uint32_t stall_ms) {
+    if (!c || workgroups_per_cu < 0 || workgroups_per_cu > 2) return c ? c->fail(BCE_ERR_ARG, "workgroups_per_cu must be 0, 1 or 2") : BCE_ERR_ARG;
+    if (stall_ms == 0 || stall_ms > 40000) return c->fail(BCE_ERR_ARG, "stall_ms must be in 1..40000");
+    c->dag_wg_per_cu = workgroups_per_cu; c->dag_placement = placement ? 1 : 0; c->dag_lazy_us = lazy_us; c->dag_stall_ms = stall_ms;
+    return BCE_OK;
+}
+
+int bce_dag_last_run(bce_ctx* c, uint64_t out[4]) {
+    if (!c || !out) return BCE_ERR_ARG;
+    for (int i = 0; i < 4; ++i) out[i] = c->dag_last[i];
+    return BCE_OK;
+}
+
+void bce_dag_destroy(bce_ctx* c, bce_dag* g) {
+    if (!g) return;
+    if (c) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); }
+    hipFree(g->d_tasks); hipFree(g->d_cons_off); hipFree(g->d_cons); hipFree(g->d_dep_init); hipFree(g->d_init); hipFree(g->d_qid);
+    hipFree(g->d_dep); hipFree(g->d_ctl); hipFree(g->d_params);
+    for (u32 q = 0; q < kDagQueues; ++q) hipFree(g->d_slots[q]);
+    delete g;
+}
+
+int bce_dag_create(bce_ctx* c, uint32_t n_tasks, const bce_gate_desc* tasks, const uint8_t* prio, bce_dag** out) {
+    if (!c || !out) return BCE_ERR_ARG;
+    *out = nullptr;
+    if (!tasks || n_tasks == 0) return c->fail(BCE_ERR_ARG, "bce_dag_create: empty task list");
+    if (!dag_kernel_available(c->P)) return c->fail(BCE_ERR_UNSUPPORTED, "bce_dag_create: no persistent kernel for this parameter class (N = 1024, 4 gadget digits, Q < 2^28 only)");
+    if ((u64)n_tasks >= (1ull << 31)) return c->fail(BCE_ERR_ARG, "bce_dag_create: too many tasks");
+    HIP_TRY(c, hipSetDevice(c->device));
+    u32 max_slot = 0;
+    for (u32 i = 0; i < n_tasks; ++i) {
+        const bce_gate_desc& g = tasks[i];
+        const bool two = g.op <= BCE_XNOR_FAST;
+        if (!two && g.op != BCE_OP_REFRESH) return c->fail(BCE_ERR_ARG, "bce_dag_create: task %u is not a bootstrapped gate (op %u)", i, g.op);
+        if (prio && prio[i] >= kDagQueues) return c->fail(BCE_ERR_ARG, "bce_dag_create: task %u has priority class %u (0..%u)", i, prio[i], kDagQueues - 1);
+        max_slot = std::max(max_slot, std::max(g.in0, g.out));
+        if (two) max_slot = std::max(max_slot, g.in1);
+    }
+    // producers by slot: SSA form is required (a slot is written once and read only by later tasks), so that the order in
+    // which the device runs independent tasks cannot matter
+    std::vector<int32_t> writer((size_t)max_slot + 1, -1);
+    std::vector<uint8_t> read_before((size_t)max_slot + 1, 0);
+    std::vector<u32> dep(n_tasks, 0), lvl(n_tasks, 1), cons_cnt(n_tasks + 1, 0);
+    std::vector<int32_t> p0(n_tasks, -1), p1(n_tasks, -1);
+    u32 depth = 0;
+    for (u32 i = 0; i < n_tasks; ++i) {
+        const bce_gate_desc& g = tasks[i];
+        const bool two = g.op <= BCE_XNOR_FAST;
+        p0[i] = writer[g.in0]; read_before[g.in0] = 1;
+        if (two) { p1[i] = writer[g.in1]; read_before[g.in1] = 1; }
+        if (p1[i] == p0[i]) p1[i] = -1;
+        if (writer[g.out] >= 0) return c->fail(BCE_ERR_ARG, "bce_dag_create: slot %u is written by tasks %d and %u (SSA form required)", g.out, writer[g.out], i);
+        if (read_before[g.out]) return c->fail(BCE_ERR_ARG, "bce_dag_create: task %u writes slot %u that an earlier task (or itself) reads", i, g.out);
+        writer[g.out] = (int32_t)i;
+        for (int32_t p : {p0[i], p1[i]})
+            if (p >= 0) { ++dep[i]; ++cons_cnt[p + 1]; lvl[i] = std::max(lvl[i], lvl[p] + 1); }
+        depth = std::max(depth, lvl[i]);
+    }
+    std::vector<u32> cons_off(cons_cnt);
+    for (u32 i = 0; i < n_tasks; ++i) cons_off[i + 1] += cons_off[i];
+    std::vector<u32> cons(std::max<u32>(1, cons_off[n_tasks])), fill(cons_off.begin(), cons_off.end() - 1);
+    for (u32 i = 0; i < n_tasks; ++i)
+        for (int32_t p : {p0[i], p1[i]}) if (p >= 0) cons[fill[p]++] = i;
+    std::vector<uint8_t> qid(n_tasks, 0);
+    if (prio) qid.assign(prio, prio + n_tasks);
+
+    struct Deleter { bce_ctx* c; void operator()(bce_dag* g) const { bce_dag_destroy(c, g); } };
+    std::unique_ptr<bce_dag, Deleter> g(new bce_dag, Deleter{c});
+    g->n_tasks = n_tasks; g->max_slot = max_slot; g->depth = depth; g->h_dep_init = dep;
+    for (u32 q = 0; q < kDagQueues; ++q) {
+        g->init_off[q] = (u32)g->init_items.size();
+        for (u32 i = 0; i < n_tasks; ++i) {
+            if (qid[i] != q) continue;
+            ++g->qcount[q];
+            if (dep[i] == 0) g->init_items.push_back(i);
+        }
+    }
+    g->init_off[kDagQueues] = (u32)g->init_items.size();
+    if (g->init_items.empty()) return c->fail(BCE_ERR_ARG, "bce_dag_create: no task is ready at the start");
+    auto up = [&](auto** dst, const auto& v) -> hipError_t {
+        using T = std::remove_reference_t<decltype(v[0])>;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(1, v.size()) * sizeof(T));
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    };
+    HIP_TRY(c, hipMalloc(&g->d_tasks, (size_t)n_tasks * sizeof(bce_gate_desc)));
+    HIP_TRY(c, hipMemcpy(g->d_tasks, tasks, (size_t)n_tasks * sizeof(bce_gate_desc), hipMemcpyHostToDevice));
+    HIP_TRY(c, up(&g->d_cons_off, cons_off));
+    HIP_TRY(c, up(&g->d_cons, cons));
+    HIP_TRY(c, up(&g->d_dep_init, dep));
+    HIP_TRY(c, up(&g->d_init, g->init_items));
+    HIP_TRY(c, up(&g->d_qid, qid));
+    HIP_TRY(c, hipMalloc(&g->d_ctl, kDagCtlWords * sizeof(u32)));
+    HIP_TRY(c, hipMalloc(&g->d_params, sizeof(DagParams)));
+    *out = g.release();
+    return BCE_OK;
+}
+
+int bce_dag_debug_block_task(bce_dag* g, uint32_t t) {
+    if (!g || t >= g->n_tasks) return BCE_ERR_ARG;
+    g->h_dep_init[t] += 1;
+    return hipMemcpy(g->d_dep_init, g->h_dep_init.data(), (size_t)g->n_tasks * sizeof(u32), hipMemcpyHostToDevice) == hipSuccess ? BCE_OK : BCE_ERR_HIP;
+}
+
+int bce_dag_run(bce_ctx* c, bce_dag* g, uint32_t instances, uint32_t slot_stride, uint32_t slot_base) {
+    if (!c || !g) return BCE_ERR_ARG;
+    if (instances == 0) return BCE_OK;
+    if (!c->have_keys) return c->fail(BCE_ERR_NO_KEYS, "bce_keygen / bce_import_keys has not been called");
+    if (instances > 1 && slot_stride <= g->max_slot) return c->fail(BCE_ERR_ARG, "bce_dag_run: slot_stride %u does not cover the DAG's slots (0..%u)", slot_stride, g->max_slot);
+    if ((u64)slot_base + g->max_slot + (u64)(instances - 1) * slot_stride >= c->pool_slots) return c->fail(BCE_ERR_POOL, "bce_dag_run: slot %llu outside the pool (%u slots)", (unsigned long long)((u64)slot_base + g->max_slot + (u64)(instances - 1) * slot_stride), c->pool_slots);
+    const u64 items = (u64)g->n_tasks * instances;
+    if (items >= 0xFFFFFFF0ull) return c->fail(BCE_ERR_ARG, "bce_dag_run: %llu bootstraps exceed one run's 32-bit item space", (unsigned long long)items);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->dag_pending >= bce_ctx::kDagRuns) { const int rc = sync_stream(c); if (rc) return rc; }
+    if (!c->d_P) HIP_TRY(c, hipMalloc(&c->d_P, sizeof(DevParams)));
+    if (!c->h_dag_status) HIP_TRY(c, hipHostMalloc(&c->h_dag_status, sizeof(bce_ctx::DagStatus) * bce_ctx::kDagRuns));
+    if (!c->h_dag_stage) HIP_TRY(c, hipHostMalloc(&c->h_dag_stage, sizeof(bce_ctx::DagStage) * bce_ctx::kDagRuns));
+    // per-run state (a dag object serves one run at a time: runs are ordered on the engine's stream)
+    if (items > g->dep_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipFree(g->d_dep); g->d_dep = nullptr;
+        HIP_TRY(c, hipMalloc(&g->d_dep, items * sizeof(u32)));
+        g->dep_cap = items;
+    }
+    DagParams D{};
+    for (u32 q = 0; q < kDagQueues; ++q) {
+        const size_t need = (size_t)g->qcount[q] * instances;
+        if (need > g->slots_cap[q]) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            hipFree(g->d_slots[q]); g->d_slots[q] = nullptr;
+            HIP_TRY(c, hipMalloc(&g->d_slots[q], need * sizeof(u32)));
+            g->slots_cap[q] = need;
+        }
+        D.slots[q] = g->d_slots[q];
+        D.qcap[q] = (u32)need;
+        D.init_off[q] = g->init_off[q];
+    }
+    D.init_off[kDagQueues] = g->init_off[kDagQueues];
+    D.tasks = g->d_tasks; D.cons_off = g->d_cons_off; D.cons = g->d_cons; D.qid = g->d_qid; D.dep_init = g->d_dep_init;
+    D.dep = g->d_dep; D.init_items = g->d_init; D.ctl = g->d_ctl;
+    D.n_tasks = g->n_tasks; D.instances = instances; D.slot_stride = slot_stride; D.slot_base = slot_base;
+    D.lazy_ticks = c->dag_lazy_us * 100u;                     // s_memrealtime: 100 MHz
+    D.stall_ticks = c->dag_stall_ms * 100000u;
+    D.policy = c->dag_placement ? 1u : 0u;
+    // one or two workgroups per CU: two run 512 bootstraps per ~3.1 ms, one runs 256 per ~1.9 ms -- with less work per
+    // dependency level than the CUs can hold alone, the shorter bootstrap wins
+    int wps = c->dag_wg_per_cu == 1 ? 2 : 4;
+    if (c->dag_wg_per_cu == 0) wps = (items / std::max<u32>(1, g->depth) <= (u64)c->P.cu_count * 3 / 4) ? 2 : 4;
+    if (const char* e = std::getenv("BCE_DAG_WPS")) { if (e[0] == '2') wps = 2; else if (e[0] == '4') wps = 4; }
+    if (const char* e = std::getenv("BCE_DAG_PLACE")) D.policy = e[0] == '0' ? 0u : 1u;
+    const char* dbg = std::getenv("BCE_DAG_DEBUG");   // development: 'r' = re-arm only, 'd' = dry run (no bootstraps)
+    if (dbg && dbg[0] == 'd') D.policy |= 2u;
+    const u32 grid = c->P.cu_count * (wps == 2 ? 1u : 2u);
+    // parameter blocks reach the device in stream order (an earlier run may still be reading the previous ones) from
+    // pinned staging entries that stay untouched until the next synchronisation
+    const int slot = c->dag_pending++;
+    c->h_dag_stage[slot].P = c->P;
+    c->h_dag_stage[slot].D = D;
+    HIP_TRY(c, hipMemcpyAsync(c->d_P, &c->h_dag_stage[slot].P, sizeof(DevParams), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(g->d_params, &c->h_dag_stage[slot].D, sizeof(DagParams), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, launch_dag_rearm(D, c->stream));
+    EventPair e0 = get_events(c, BCE_BR_DAG);
+    hipEventRecord(e0.a, c->stream);
+    if (!(dbg && dbg[0] == 'r')) HIP_TRY(c, launch_bootstrap_dag(c->P, c->d_P, g->d_params, wps, grid, c->stream));
+    hipEventRecord(e0.b, c->stream);
+    c->pending.push_back(e0);
+    c->dag_expected[slot] = items;
+    c->dag_wps_used[slot] = wps;
+    HIP_TRY(c, hipMemcpyAsync(&c->h_dag_status[slot], g->d_ctl + kDagAbort, sizeof(bce_ctx::DagStatus), hipMemcpyDeviceToHost, c->stream));
+    c->timing.br_launches[BCE_BR_DAG] += 1;
+    c->timing.br_bootstraps[BCE_BR_DAG] += items;
+    c->timing.blind_rotate_launches += 1;
+    c->timing.fused_tail_launches += 1;
+    c->timing.bootstraps += items;
     return BCE_OK;
 }
 
@@ -951,10 +1187,10 @@ int bce_timing_reset(bce_ctx* c) {
 
 int bce_timing_get(bce_ctx* c, bce_timing* out) {
     if (!c || !out) return BCE_ERR_ARG;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int rc = sync_stream(c);
     drain_timing(c);
     *out = c->timing;
-    return BCE_OK;
+    return rc;
 }
 
 uint32_t bce_forward_transforms_per_step(const bce_ctx* c) { return c ? 2 * c->dG - (c->P.fold ? 2 : 0) : 0; }

@@ -592,8 +592,8 @@ __device__ __forceinline__ u32 gate_const(u32 op, u32 q) {
 // into the 4 accumulator words read at accp, written to accw (also returned in a[], values < 2Q when LAZY).
 // I^a' and I^-a' for I = psi^(N/2): the 4 positions sit at evaluation points whose exponents differ by
 // multiples of (N/2)*a' (brv(p0+e) = brv(p0) + {0,2,1,3}*N/4).
-template <int LOGN, bool LAZY>
-__device__ __forceinline__ void ginx_mac_tail(const DevParams& P, __amdgpu_buffer_rsrc_t psi_rsrc, u32 Q, u32 ap, uint2 Ia,
+template <int LOGN, bool LAZY, typename PT>
+__device__ __forceinline__ void ginx_mac_tail(const PT& P, __amdgpu_buffer_rsrc_t psi_rsrc, u32 Q, u32 ap, uint2 Ia,
                                               uint2 Ina, u32 p0, const u32* accp, u32* accw, const u64 (&sp)[4],
                                               const u64 (&sn)[4], u32 (&a)[4]) {
     constexpr u32 N = 1u << LOGN;
@@ -631,8 +631,8 @@ __device__ __forceinline__ void ginx_mac_tail(const DevParams& P, __amdgpu_buffe
 // Common start of a gate bootstrap: twiddles into LDS, EvalBinGate's LWE preparation (ct1 + ct2 with the
 // folded EvalNOTs, or ct + q/4 for a refresh) into av[0..n], BootstrapGateCore's test vector into acc
 // (evaluation form).  Ends with a workgroup barrier.
-template <int LOGN, bool LAZY, u32 T>
-__device__ __forceinline__ void bootstrap_prologue(const DevParams& P, const bce_gate_desc& g, u32 soff, uint2* twf, u32* acc,
+template <int LOGN, bool LAZY, u32 T, typename PT>
+__device__ __forceinline__ void bootstrap_prologue(const PT& P, const bce_gate_desc& g, u32 soff, uint2* twf, u32* acc,
                                                    u32* av, u32 tid, u32 lane, u32 wave) {
     using C = Cfg<LOGN>;
     constexpr int N = C::N, NP = C::NP;
@@ -1046,8 +1046,8 @@ __device__ __forceinline__ void split_inverse_rest(const SplitInv<REGTW>& S, con
 //   coef : [2][N] coefficient-form accumulator in LDS        rowidx : [N * dKS] row numbers in LDS
 //   red  : [SL][Gv * VW] u64 partial sums in LDS (SL row slices, one per RW = ceil(Gv / 64) waves)
 // T threads (a multiple of 64); every thread of the workgroup must call it.
-template <typename KT, u32 T>
-__device__ __forceinline__ void fused_tail(const DevParams& P, const u32* coef, u32* rowidx, u64* red, u32* out, u32 boot,
+template <typename KT, u32 T, typename PT>
+__device__ __forceinline__ void fused_tail(const PT& P, const u32* coef, u32* rowidx, u64* red, u32* out, u32 boot,
                                            u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
     constexpr u32 VW = 16 / sizeof(KT), W = T / 64;
     const u32 N = P.N, n = P.n, qKS = P.qKS, B = P.baseKS, D = P.dKS, Q = P.Q;
@@ -1145,28 +1145,32 @@ __device__ __forceinline__ void fused_tail(const DevParams& P, const u32* coef, 
 //   the accumulator rows where the digit-0 rows used to be: 6 forward transforms per step instead of 8, same
 //   accumulator words.  The evaluation-form accumulator is double-buffered between `acc` and the two digit rows that
 //   became free (other threads read a component's words as a MAC row while its owner writes the new ones).
-template <int DG, int WPS, bool AP = false, bool FUSE = false, bool FOLD = false>  // WPS = waves per SIMD the register budget allows: 2 (one workgroup per CU) or 4 (two)
-__global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
-                                                                   u32 slot_stride, u32* __restrict__ acc_out,
-                                                                   u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
+// lat_bootstrap: ONE gate bootstrap by the calling workgroup (all 128 DG threads), the body shared by the per-frontier
+// kernel k_blind_rotate_lat and the dependency-driven persistent kernel k_bootstrap_dag.  g: the gate, soff: slot offset
+// of the instance, boot: index of this bootstrap in acc_out / the debug buffers (acc_out may be null).
+// WPS = waves per SIMD the register budget allows: 2 (one workgroup per CU) or 4 (two)
+template <int DG, int WPS, bool AP, bool FUSE, bool FOLD, bool PERSIST = false, typename PT>
+__device__ __forceinline__ void lat_bootstrap(const PT& P, const bce_gate_desc g, const u32 soff, const u32 boot, u32* smem,
+                                              u32* __restrict__ acc_out, u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
     static_assert(DG == 4, "the split inverse transform is laid out for 8 waves");
     constexpr int LOGN = 10;
     using C = Cfg<LOGN>;
     constexpr int N = C::N, NP = C::NP;
     constexpr u32 R = 2 * DG, T = 64 * R, XB = 1280;
-    extern __shared__ __align__(16) u32 smem[];
     uint2* twf = reinterpret_cast<uint2*>(smem);
     u32* acc = reinterpret_cast<u32*>(twf + N);  // [2][NP]
     u32* dct = acc + 2 * NP;                     // [R][NP]
     u32* xab = dct + R * NP;                     // [2 polynomials][2 buffers][XB]
     u32* av = xab + 4 * XB;
 
-    const u32 tid = threadIdx.x;
+    u32 tid_ = threadIdx.x;
+    // opaque inside the persistent kernel's loop: nothing derived from the thread index is hoisted out of the bootstrap
+    // (and then kept alive, i.e. spilled, across it)
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid_));
+    const u32 tid = tid_;
     const u32 lane = tid & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 Q = P.Q, q = P.q, qm = q - 1, n = P.n;
-    const bce_gate_desc g = descs[blockIdx.x % n_desc];
-    const u32 soff = (blockIdx.x / n_desc) * slot_stride;
     bootstrap_prologue<LOGN, true, T>(P, g, soff, twf, acc, av, tid, lane, wave);
 
     const u32 c = wave >> 2;  // this wave's inverse-transform group = accumulator component
@@ -1324,9 +1328,11 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
     {
         u32 x[4];
         split_inverse_rest(S, twf, xa, xb, Q, P.mu32, ninv, wlast, x, [](auto) {});
-        u32* out = acc_out + ((size_t)blockIdx.x * 2 + c) * N + S.t;
+        if (acc_out) {
+            u32* out = acc_out + ((size_t)boot * 2 + c) * N + S.t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[256 * r] = x[r];
+            for (int r = 0; r < 4; ++r) out[256 * r] = x[r];
+        }
         if constexpr (FUSE) {
             // coefficient-form accumulator into LDS (the evaluation-form copy in `acc` is dead: its pass 0 went to xa)
 #pragma unroll
@@ -1340,9 +1346,18 @@ __global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P,
         u32* rowidx = dct;
         u64* red = reinterpret_cast<u64*>(dct + ((N * P.dKS + 3) & ~3u));
         u32* outp = P.pool + (size_t)(g.out + soff) * P.pool_stride;
-        if (P.ksk_u16) fused_tail<uint16_t, T>(P, acc, rowidx, red, outp, blockIdx.x, dbg_lweN, dbg_ks);
-        else fused_tail<u32, T>(P, acc, rowidx, red, outp, blockIdx.x, dbg_lweN, dbg_ks);
+        if (P.ksk_u16) fused_tail<uint16_t, T>(P, acc, rowidx, red, outp, boot, dbg_lweN, dbg_ks);
+        else fused_tail<u32, T>(P, acc, rowidx, red, outp, boot, dbg_lweN, dbg_ks);
     }
+}
+
+template <int DG, int WPS, bool AP = false, bool FUSE = false, bool FOLD = false>
+__global__ __launch_bounds__(128 * DG, WPS) void k_blind_rotate_lat(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
+                                                                   u32 slot_stride, u32* __restrict__ acc_out,
+                                                                   u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
+    extern __shared__ __align__(16) u32 smem[];
+    lat_bootstrap<DG, WPS, AP, FUSE, FOLD>(P, descs[blockIdx.x % n_desc], (blockIdx.x / n_desc) * slot_stride, blockIdx.x, smem,
+                                           acc_out, dbg_lweN, dbg_ks);
 }
 
 // LDS the fused tail needs inside the digit rows + exchange buffers of k_blind_rotate_lat (T = 512 threads)
@@ -1362,6 +1377,217 @@ size_t blind_rotate_lds_bytes(const DevParams& P) {
     const size_t N = P.N, NP = N + (N >> 6) * 4, R = 2 * P.dG;
     return (2 * N + (2 + R) * NP + ((P.n + 1 + 3) & ~3u)) * sizeof(u32);
 }
+
+// ---------------------------------------------------------------------------------------
+// dependency-driven persistent kernel: the whole bootstrap DAG in ONE launch
+// ---------------------------------------------------------------------------------------
+// What the reference does between two gate evaluations -- Circuit::_ManageGates marks the gates whose inputs have all
+// arrived as ready (src/circuit.cpp:575-683), Circuit::_ExecuteGates runs the ready ones in a parallel region and
+// retires them (src/circuit.cpp:685-817) -- happens here on the device, per bootstrap instead of per frontier:
+//   * dep[instance][task] counts the producers of a task that have not finished (0..2, from the slot numbers);
+//   * the workgroup that finished a bootstrap (its refreshed ciphertext is in the pool: fused tail) releases its stores at
+//     agent scope, decrements its consumers' counters with agent-scope atomics and pushes every consumer that reached
+//     zero to the ready queue of its priority class: idx = tail++ ; slots[idx] = item + 1;
+//   * an idle workgroup polls the queue heads (relaxed agent-scope loads + s_sleep, ONE lane), claims the head entry with
+//     a compare-and-swap on `head`, performs ONE agent-scope acquire (this CU's L1 holds no fresh copy of other CUs'
+//     stores) and runs the bootstrap.  Queue entries are written once per evaluation and never wrap: no ABA.
+// Hand-off protocol = the plain-payload / release-fence / relaxed-flag form of the MI355X guide (Guideline 16): every
+// storing wave drains (vmcnt(0)), workgroup barrier, one wave fences + drains, then the atomics; the consumer polls
+// relaxed, fences once, drains, workgroup barrier, then plain loads.
+// Progress: a workgroup never waits while it owns something another one needs (it either runs a bootstrap, which ends,
+// or polls), so the launch completes for any residency; the launcher still sizes the grid to the resident count so that
+// no workgroup sits unscheduled.  Every spin is bounded: no completion anywhere for stall_ticks sets the abort word,
+// everyone leaves, the host reports BCE_ERR_STATE.
+// Placement (policy bit 0): one bootstrap alone on a CU takes ~2.0 ms, two sharing it ~3.1 ms each, so a narrow frontier
+// should spread over CUs first.  A workgroup knows its CU (HW_ID / XCC_ID) and how many workgroups on it are running
+// (cu_busy[key]); it claims at once only when its CU is idle and it is the CU's first workgroup -- otherwise it leaves a
+// short queue (< kDagDeep ready entries) alone for lazy_ticks, which an idle CU's eager workgroup needs ~1 us to take.
+namespace {
+constexpr u32 kDagExit = 0xFFFFFFFFu, kDagDeep = 8;
+// every shared word is accessed through the GLOBAL address space (global_* instructions, never flat_*)
+typedef __attribute__((address_space(1))) u32 gu32;
+__device__ __forceinline__ u32 dag_ld(const u32* p) { return __hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void dag_st(u32* p, u32 v) { __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u32 dag_add(u32* p, u32 v) { return __hip_atomic_fetch_add((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ONE thread: next item of the highest non-empty priority class, or kDagExit when every class has been claimed to
+// its end (or the run was aborted)
+template <typename DT>
+__device__ __forceinline__ u32 dag_acquire(const DT& D, const u32* my_busy, bool first_on_cu) {
+    u32* const ctl = D.ctl;
+    u32 last_h[kDagQueues];
+    u64 seen[kDagQueues];
+#pragma unroll
+    for (u32 q = 0; q < kDagQueues; ++q) { last_h[q] = kDagExit; seen[q] = 0; }
+    u64 t_progress = __builtin_amdgcn_s_memrealtime();
+    u32 last_done = kDagExit;
+    for (u32 spin = 0;; ++spin) {
+        const u64 now = __builtin_amdgcn_s_memrealtime();
+        bool lazy = false;
+        if (D.policy & 1u) lazy = !first_on_cu || dag_ld(my_busy) != 0;
+        bool alive = false, lost = false;
+#pragma unroll
+        for (u32 q = 0; q < kDagQueues; ++q) {
+            if (lost || D.qcap[q] == 0) continue;
+            const u32 h = dag_ld(ctl + q * kDagCtlStride);
+            if (h >= D.qcap[q]) continue;
+            alive = true;
+            const u32 v = dag_ld(D.slots[q] + h);
+            if (!v) continue;
+            if (lazy) {
+                const u32 t = dag_ld(ctl + q * kDagCtlStride + 1);
+                if (t - h < kDagDeep) {
+                    if (h != last_h[q]) { last_h[q] = h; seen[q] = now; continue; }
+                    if (now - seen[q] < D.lazy_ticks) continue;
+                    dag_add(ctl + kDagLazyWaits, 1);
+                }
+            }
+            u32 expect = h;
+            if (__hip_atomic_compare_exchange_strong((gu32*)(ctl + q * kDagCtlStride), &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT))
+                return v - 1;
+            lost = true;   // another workgroup took it: look again at once
+        }
+        if (lost) continue;
+        if (!alive) return kDagExit;
+        if ((spin & 15u) == 15u) {
+            if (dag_ld(ctl + kDagAbort)) return kDagExit;
+            const u32 d = dag_ld(ctl + kDagDone);
+            if (d != last_done) { last_done = d; t_progress = now; }
+            else if (now - t_progress > D.stall_ticks) { dag_st(ctl + kDagAbort, 1u); return kDagExit; }
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+}  // namespace
+
+__global__ void k_dag_rearm(DagParams D) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t items = (size_t)D.n_tasks * D.instances;
+    for (size_t i = i0; i < items; i += stride) D.dep[i] = D.dep_init[i % D.n_tasks];
+    for (u32 q = 0; q < kDagQueues; ++q) {
+        const u32 ninit = (D.init_off[q + 1] - D.init_off[q]) * D.instances;
+        for (size_t j = i0; j < D.qcap[q]; j += stride) {
+            u32 v = 0;
+            if (j < ninit) {   // initially ready: task-major, the instances of one task next to each other
+                const u32 ti = (u32)(j / D.instances), k = (u32)(j % D.instances);
+                v = k * D.n_tasks + D.init_items[D.init_off[q] + ti] + 1u;
+            }
+            D.slots[q][j] = v;
+        }
+        if (i0 == 0) { D.ctl[q * kDagCtlStride] = 0; D.ctl[q * kDagCtlStride + 1] = ninit; }
+    }
+    for (size_t j = i0 + kDagAbort; j < kDagCtlWords; j += stride) D.ctl[j] = 0;
+}
+
+// Pp / Dp point to the engine's DevParams and the run's DagParams in device memory.  They are not by-value arguments:
+// kernel arguments are loaded at entry and would stay live in scalar registers across the whole persistent loop (the
+// per-frontier kernel lets most of them die after its prologue).  Each iteration reads them through a constant-address-
+// space pointer made opaque inside the loop: scalar loads where a field is needed, nothing hoisted out of the loop.
+typedef const __attribute__((address_space(4))) DevParams ConstDevParams;
+typedef const __attribute__((address_space(4))) DagParams ConstDagParams;
+template <typename C, typename S>
+__device__ __forceinline__ C* as_constant(const S* p) {
+    C* c = (C*)(uintptr_t)p;
+    asm volatile("" : "+s"(c));
+    return c;
+}
+
+template <int WPS, bool AP, bool FOLD>
+__global__ __launch_bounds__(512, WPS) void k_bootstrap_dag(const DevParams* Pp, const DagParams* Dp) {
+    extern __shared__ __align__(16) u32 smem[];
+    // four words in front of the LDS layout of lat_bootstrap: [0] the item the workgroup runs next, [1] "first workgroup
+    // of its CU", [2] the CU's key
+    u32* const mbox = smem;
+    if (threadIdx.x == 0) {
+        // which CU this workgroup sits on: HW_ID[15:8] = (SE, SH, CU), XCC_ID[3:0]
+        const u32 hwid = __builtin_amdgcn_s_getreg((31u << 11) | 4u), xcc = __builtin_amdgcn_s_getreg((31u << 11) | 20u);
+        const u32 key = ((xcc & 15u) << 8) | ((hwid >> 8) & 255u);
+        mbox[1] = dag_add(Dp->ctl + kDagCuArrive + key, 1u) != 1u;   // only a CU's second arrival yields
+        mbox[2] = key;
+    }
+    for (;;) {
+        // The thread index is made opaque in every iteration and at every use: a comparison the optimiser can prove
+        // loop-invariant lets it thread the back edge past the `== 0` test, i.e. split the loop into a path for thread 0
+        // and one for the others; the wave then runs them one after the other -- lanes 1..63 of wave 0 spin in "their" loop
+        // through the barriers below while lane 0 never gets to claim an item (observed: a hang, and bootstraps run on
+        // stale mailbox contents).
+        u32 tid_a = threadIdx.x;
+        asm volatile("" : "+v"(tid_a));
+        if (tid_a == 0) {
+            ConstDagParams& D = *as_constant<ConstDagParams>(Dp);
+            u32* const my_busy = D.ctl + kDagCuBusy + mbox[2];
+            const u32 it = dag_acquire(D, my_busy, mbox[1] != 0);
+            if (it != kDagExit) {
+                dag_add(my_busy, 1u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            mbox[0] = it;
+        }
+        __syncthreads();
+        {
+            const u32 item = __builtin_amdgcn_readfirstlane(mbox[0]);
+            if (item == kDagExit) break;
+            ConstDagParams& D = *as_constant<ConstDagParams>(Dp);
+            const u32 nt = D.n_tasks, k = item / nt, t = item - k * nt;
+            // policy bit 1 (development): walk the DAG without running the bootstraps -- the scheduler's own time
+            if (!(D.policy & 2u))
+            lat_bootstrap<4, WPS, AP, true, FOLD, true>(*as_constant<ConstDevParams>(Pp), D.tasks[t], D.slot_base + k * D.slot_stride, 0, smem + 4,
+                                                       nullptr, nullptr, nullptr);
+        }
+        // publish: every storing wave drains, barrier, one wave releases at agent scope, then the counters
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        u32 tid_p = threadIdx.x;
+        asm volatile("" : "+v"(tid_p));
+        if (tid_p < 64) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ConstDagParams& D = *as_constant<ConstDagParams>(Dp);
+            const u32 item = __builtin_amdgcn_readfirstlane(mbox[0]);
+            const u32 nt = D.n_tasks, k = item / nt, t = item - k * nt;
+            u32* const dep = D.dep + (size_t)k * nt;
+            const u32 c1 = D.cons_off[t + 1];
+            for (u32 i = D.cons_off[t] + tid_p; i < c1; i += 64) {
+                const u32 c = D.cons[i];
+                if (__hip_atomic_fetch_sub((gu32*)(dep + c), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) {
+                    const u32 q = D.qid[c];
+                    const u32 idx = dag_add(D.ctl + q * kDagCtlStride + 1, 1u);
+                    dag_st(D.slots[q] + idx, k * nt + c + 1u);
+                }
+            }
+            if (tid_p == 0) {
+                dag_add(D.ctl + kDagDone, 1u);
+                __hip_atomic_fetch_sub((gu32*)(D.ctl + kDagCuBusy + mbox[2]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+bool dag_kernel_available(const DevParams& P) {
+    return !P.is64 && P.variant != 1 && P.logN == 10 && P.dG == 4 && P.lazy && fused_tail_fits(P);
+}
+
+hipError_t launch_dag_rearm(const DagParams& D, hipStream_t s) {
+    hipLaunchKernelGGL(k_dag_rearm, dim3(1024), dim3(256), 0, s, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_bootstrap_dag(const DevParams& P, const DevParams* d_P, const DagParams* d_params, int wps, u32 grid, hipStream_t s) {
+    if (!dag_kernel_available(P)) return hipErrorInvalidValue;
+    using DagKernel = void (*)(const DevParams*, const DagParams*);
+    const bool ap = P.method_ap != 0, x1 = wps <= 2;
+    DagKernel k;
+    if (P.fold) k = ap ? (x1 ? k_bootstrap_dag<2, true, true> : k_bootstrap_dag<4, true, true>) : (x1 ? k_bootstrap_dag<2, false, true> : k_bootstrap_dag<4, false, true>);
+    else k = ap ? (x1 ? k_bootstrap_dag<2, true, false> : k_bootstrap_dag<4, true, false>) : (x1 ? k_bootstrap_dag<2, false, false> : k_bootstrap_dag<4, false, false>);
+    const size_t lds = blind_rotate_lat_lds_bytes(P) + 16;   // + the mailbox words in front
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, d_P, d_params);
+    return hipGetLastError();
+}
+
 
 namespace {
 using BrKernel = void (*)(DevParams, const bce_gate_desc*, u32, u32, u32*);

@@ -67,6 +67,47 @@ struct DevParams {
 // LDS bytes the blind-rotation kernel needs for these parameters
 size_t blind_rotate_lds_bytes(const DevParams& P);
 
+// ---- dependency-driven evaluation of a whole bootstrap DAG by ONE persistent launch (k_bootstrap_dag) ----------------
+// Replaces the manager <-> executor loop of the reference (src/circuit.cpp:575-683 ready-gate rule, :698-710 parallel
+// region) on the device: every (task, instance) pair has a counter of unfinished producers; a workgroup that finishes a
+// bootstrap decrements its consumers' counters and pushes those that reach zero to a ready queue; idle workgroups pull
+// from the queues.  No kernel boundary and no device-wide barrier between dependent bootstraps.
+constexpr u32 kDagQueues = 4;        // priority classes (0 = most urgent)
+constexpr u32 kDagCtlStride = 32;    // u32 words per queue in the control block: [0] head, [1] tail (own 128-byte line)
+constexpr u32 kDagCuKeys = 4096;     // (XCC id, SE, SH, CU) keys of the placement table
+// control block (u32 words): queue q at q * kDagCtlStride; then the words below; then the per-CU tables
+constexpr u32 kDagAbort = kDagQueues * kDagCtlStride;      // != 0: a poller gave up (code)
+constexpr u32 kDagDone = kDagAbort + 1;                    // bootstraps completed
+constexpr u32 kDagLazyWaits = kDagAbort + 2;               // diagnostics: claims a half-busy CU delayed for an idle one
+constexpr u32 kDagCuArrive = kDagAbort + 32;               // [kDagCuKeys] workgroups that announced themselves per CU
+constexpr u32 kDagCuBusy = kDagCuArrive + kDagCuKeys;      // [kDagCuKeys] workgroups running a bootstrap per CU
+constexpr u32 kDagCtlWords = kDagCuBusy + kDagCuKeys;
+struct DagParams {
+    const bce_gate_desc* tasks;   // [n_tasks] topological order, SSA slots
+    const u32* cons_off;          // [n_tasks + 1]
+    const u32* cons;              // consumers of every task
+    const uint8_t* qid;           // [n_tasks] priority class
+    const u32* dep_init;          // [n_tasks] producers inside the DAG (0..2)
+    u32* dep;                     // [instances][n_tasks] unfinished producers
+    u32* slots[kDagQueues];       // queue entries: item + 1 (0 = not yet pushed); item = instance * n_tasks + task
+    u32 qcap[kDagQueues];         // entries the queue will ever receive (tasks of that class x instances)
+    const u32* init_items;        // initially ready tasks of every class, concatenated; init_off[q] .. init_off[q + 1]
+    u32 init_off[kDagQueues + 1];
+    u32* ctl;                     // control block, kDagCtlWords words
+    u32 n_tasks, instances, slot_stride, slot_base;   // instance k: slot numbers + slot_base + k * slot_stride
+    u32 lazy_ticks;               // 100 MHz ticks a workgroup on a half-busy CU leaves a lone ready item to an idle CU
+    u32 stall_ticks;              // 100 MHz ticks without any push after which a poller sets the abort word
+    u32 policy;                   // bit 0: placement-aware claims (idle CUs first)
+};
+// rearm = reset counters / queues for one evaluation; then the persistent launch.  wps = 2: one workgroup per CU
+// (256-register build), 4: two per CU.  grid = resident workgroups (never more).
+hipError_t launch_dag_rearm(const DagParams& D, hipStream_t s);
+// d_P / d_params: the engine's DevParams and the run's DagParams in DEVICE memory (the kernel reads their fields where
+// it needs them instead of holding kernel arguments in registers across its loop)
+hipError_t launch_bootstrap_dag(const DevParams& P, const DevParams* d_P, const DagParams* d_params, int wps, u32 grid,
+                                hipStream_t s);
+bool dag_kernel_available(const DevParams& P);
+
 // acc_out: u32 [n_boot][2][N], COEFFICIENT domain, values in [0, Q)
 // *kernel_id (optional) receives the enum bce_br_kernel value of the kernel that was launched
 // *tail_fused (optional) is set when the launched kernel also ran the tail of EvalBinGate (extract, ModSwitch,
