@@ -120,7 +120,7 @@ struct bce_ctx {
     DevParams* d_P = nullptr;
     int dag_wg_per_cu = 0, dag_placement = 1;
     uint32_t dag_lazy_us = 20, dag_stall_ms = 4000;
-    struct DagStatus { uint32_t abort, done, lazy_waits, pad; };
+    struct DagStatus { uint32_t abort, done, lazy_waits, pad; uint64_t busy_ticks, wait_ticks; };
     static constexpr int kDagRuns = 32;
     DagStatus* h_dag_status = nullptr;        // pinned, kDagRuns entries
     struct DagStage { DevParams P; DagParams D; };
@@ -128,7 +128,7 @@ struct bce_ctx {
     uint64_t dag_expected[kDagRuns] = {0};
     int dag_wps_used[kDagRuns] = {0};
     int dag_pending = 0;
-    uint64_t dag_last[4] = {0, 0, 0, 0};
+    uint64_t dag_last[6] = {0, 0, 0, 0, 0, 0};
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -520,6 +520,7 @@ int check_dag_runs(bce_ctx* c) {
     for (int i = 0; i < c->dag_pending; ++i) {
         const bce_ctx::DagStatus& st = c->h_dag_status[i];
         c->dag_last[0] = st.done; c->dag_last[1] = st.lazy_waits; c->dag_last[2] = st.abort; c->dag_last[3] = (u64)c->dag_wps_used[i] / 2;
+        c->dag_last[4] = st.busy_ticks; c->dag_last[5] = st.wait_ticks;
         if (st.abort != 0 || st.done != c->dag_expected[i])
             rc = c->fail(BCE_ERR_STATE, "bce_dag_run: the device scheduler gave up (abort code %u, %u of %llu bootstraps completed, no progress for %u ms)",
                          st.abort, st.done, (unsigned long long)c->dag_expected[i], c->dag_stall_ms);
@@ -1007,9 +1008,9 @@ int bce_dag_set_limits(bce_ctx* c, int workgroups_per_cu, int placement, uint32_
     return BCE_OK;
 }
 
-int bce_dag_last_run(bce_ctx* c, uint64_t out[4]) {
+int bce_dag_last_run(bce_ctx* c, uint64_t out[6]) {
     if (!c || !out) return BCE_ERR_ARG;
-    for (int i = 0; i < 4; ++i) out[i] = c->dag_last[i];
+    for (int i = 0; i < 6; ++i) out[i] = c->dag_last[i];
     return BCE_OK;
 }
 

@@ -1388,9 +1388,10 @@ size_t blind_rotate_lds_bytes(const DevParams& P) {
 //   * the workgroup that finished a bootstrap (its refreshed ciphertext is in the pool: fused tail) releases its stores at
 //     agent scope, decrements its consumers' counters with agent-scope atomics and pushes every consumer that reached
 //     zero to the ready queue of its priority class: idx = tail++ ; slots[idx] = item + 1;
-//   * an idle workgroup polls the queue heads (relaxed agent-scope loads + s_sleep, ONE lane), claims the head entry with
-//     a compare-and-swap on `head`, performs ONE agent-scope acquire (this CU's L1 holds no fresh copy of other CUs'
-//     stores) and runs the bootstrap.  Queue entries are written once per evaluation and never wrap: no ABA.
+//   * an idle workgroup polls the queues' head / tail words (relaxed agent-scope loads + s_sleep, ONE lane), takes a
+//     ticket on a class with a backlog (fetch-add on `head`), waits for that entry if need be, performs ONE agent-scope
+//     acquire (this CU's L1 holds no fresh copy of other CUs' stores) and runs the bootstrap.  Queue entries are written
+//     once per evaluation and never wrap.
 // Hand-off protocol = the plain-payload / release-fence / relaxed-flag form of the MI355X guide (Guideline 16): every
 // storing wave drains (vmcnt(0)), workgroup barrier, one wave fences + drains, then the atomics; the consumer polls
 // relaxed, fences once, drains, workgroup barrier, then plain loads.
@@ -1398,12 +1399,13 @@ size_t blind_rotate_lds_bytes(const DevParams& P) {
 // or polls), so the launch completes for any residency; the launcher still sizes the grid to the resident count so that
 // no workgroup sits unscheduled.  Every spin is bounded: no completion anywhere for stall_ticks sets the abort word,
 // everyone leaves, the host reports BCE_ERR_STATE.
-// Placement (policy bit 0): one bootstrap alone on a CU takes ~2.0 ms, two sharing it ~3.1 ms each, so a narrow frontier
-// should spread over CUs first.  A workgroup knows its CU (HW_ID / XCC_ID) and how many workgroups on it are running
-// (cu_busy[key]); it claims at once only when its CU is idle and it is the CU's first workgroup -- otherwise it leaves a
-// short queue (< kDagDeep ready entries) alone for lazy_ticks, which an idle CU's eager workgroup needs ~1 us to take.
+// Placement (policy bit 0): one bootstrap alone on a CU takes 2.0-2.5 ms, two sharing it ~3.1 ms each, so a narrow
+// frontier should spread over CUs first.  A workgroup knows its CU (HW_ID / XCC_ID) and how many workgroups on it are
+// running (cu_busy[key]); the control line counts the CUs on which none is (idle_cus).  The first workgroup of an idle CU
+// claims at once; any other one only when the backlog exceeds what the idle CUs will take (seen on two polls in a row),
+// or after it has watched the same queue head for lazy_ticks.
 namespace {
-constexpr u32 kDagExit = 0xFFFFFFFFu, kDagDeep = 8;
+constexpr u32 kDagExit = 0xFFFFFFFFu;
 // every shared word is accessed through the GLOBAL address space (global_* instructions, never flat_*)
 typedef __attribute__((address_space(1))) u32 gu32;
 __device__ __forceinline__ u32 dag_ld(const u32* p) { return __hip_atomic_load((const gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1411,52 +1413,85 @@ __device__ __forceinline__ void dag_st(u32* p, u32 v) { __hip_atomic_store((gu32
 __device__ __forceinline__ u32 dag_add(u32* p, u32 v) { return __hip_atomic_fetch_add((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ONE thread: next item of the highest non-empty priority class, or kDagExit when every class has been claimed to
-// its end (or the run was aborted)
+// its end (or the run was aborted).
+// Claiming is wait-free: the poller reads the eight head / tail words (one 32-byte block, one cache line for every
+// poller of the chip), and only when a class shows a backlog (tail > head) does it take a TICKET with one fetch-add on
+// that head; the entry of that ticket is its own word to wait for (normally already written; when more pollers than
+// entries raced for the backlog, the ticket is a claim on the next entry the class receives).  A compare-and-swap on
+// the head instead makes every idle workgroup retry against every other one: measured 5.6 us per claim, serialised,
+// with 512 workgroups (180 k claims/s for the whole chip -- the scheduler itself was the bottleneck).
 template <typename DT>
 __device__ __forceinline__ u32 dag_acquire(const DT& D, const u32* my_busy, bool first_on_cu) {
     u32* const ctl = D.ctl;
     u32 last_h[kDagQueues];
     u64 seen[kDagQueues];
+    bool over[kDagQueues];   // the backlog of the class exceeded the idle CUs at the previous poll
 #pragma unroll
-    for (u32 q = 0; q < kDagQueues; ++q) { last_h[q] = kDagExit; seen[q] = 0; }
+    for (u32 q = 0; q < kDagQueues; ++q) { last_h[q] = kDagExit; seen[q] = 0; over[q] = false; }
     u64 t_progress = __builtin_amdgcn_s_memrealtime();
     u32 last_done = kDagExit;
     for (u32 spin = 0;; ++spin) {
         const u64 now = __builtin_amdgcn_s_memrealtime();
+        u32 hd[kDagQueues], tl[kDagQueues];
+#pragma unroll
+        for (u32 q = 0; q < kDagQueues; ++q) { hd[q] = dag_ld(ctl + q); tl[q] = dag_ld(ctl + kDagQueues + q); }
         bool lazy = false;
-        if (D.policy & 1u) lazy = !first_on_cu || dag_ld(my_busy) != 0;
-        bool alive = false, lost = false;
+        u32 idle_cus = 0;
+        if (D.policy & 1u) {
+            lazy = !first_on_cu || dag_ld(my_busy) != 0;
+            if (lazy) idle_cus = dag_ld(ctl + kDagIdleCus);
+        }
+        bool alive = false;
+        u32 pick = kDagQueues;
 #pragma unroll
         for (u32 q = 0; q < kDagQueues; ++q) {
-            if (lost || D.qcap[q] == 0) continue;
-            const u32 h = dag_ld(ctl + q * kDagCtlStride);
-            if (h >= D.qcap[q]) continue;
+            if (hd[q] >= D.qcap[q]) continue;
             alive = true;
-            const u32 v = dag_ld(D.slots[q] + h);
-            if (!v) continue;
+            const u32 backlog = tl[q] - hd[q];
+            if ((int)backlog <= 0) { over[q] = false; continue; }
+            if (pick != kDagQueues) continue;
             if (lazy) {
-                const u32 t = dag_ld(ctl + q * kDagCtlStride + 1);
-                if (t - h < kDagDeep) {
-                    if (h != last_h[q]) { last_h[q] = h; seen[q] = now; continue; }
+                // what the idle compute units can take is left to them: claim only a backlog beyond that (twice in a
+                // row: the idle ones need a poll to react), or an entry nobody wanted for lazy_ticks
+                const bool was_over = over[q];
+                over[q] = (int)backlog > (int)idle_cus;
+                if (!(over[q] && was_over)) {
+                    if (hd[q] != last_h[q]) { last_h[q] = hd[q]; seen[q] = now; continue; }
                     if (now - seen[q] < D.lazy_ticks) continue;
                     dag_add(ctl + kDagLazyWaits, 1);
                 }
             }
-            u32 expect = h;
-            if (__hip_atomic_compare_exchange_strong((gu32*)(ctl + q * kDagCtlStride), &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT))
-                return v - 1;
-            lost = true;   // another workgroup took it: look again at once
+            pick = q;
         }
-        if (lost) continue;
+        if (pick != kDagQueues) {
+            const u32 t = dag_add(ctl + pick, 1u);
+            if (t < D.qcap[pick]) {
+                const u32* const entry = D.slots[pick] + t;
+                for (u32 w = 0;; ++w) {
+                    const u32 v = dag_ld(entry);
+                    if (v) return v - 1;
+                    if ((w & 63u) == 63u) {
+                        if (dag_ld(ctl + kDagAbort)) return kDagExit;
+                        const u64 tw = __builtin_amdgcn_s_memrealtime();
+                        const u32 d = dag_ld(ctl + kDagDone);
+                        if (d != last_done) { last_done = d; t_progress = tw; }
+                        else if (tw - t_progress > D.stall_ticks) { dag_st(ctl + kDagAbort, 2u); return kDagExit; }
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            continue;   // a ticket beyond the class's last entry: nothing there, look again
+        }
         if (!alive) return kDagExit;
-        if ((spin & 15u) == 15u) {
+        if ((spin & 7u) == 7u) {
             if (dag_ld(ctl + kDagAbort)) return kDagExit;
             const u32 d = dag_ld(ctl + kDagDone);
             if (d != last_done) { last_done = d; t_progress = now; }
             else if (now - t_progress > D.stall_ticks) { dag_st(ctl + kDagAbort, 1u); return kDagExit; }
         }
-        __builtin_amdgcn_s_sleep(32);
+        // idle: poll gently (the wake-up delay is microseconds on a bootstrap of milliseconds; hundreds of workgroups
+        // re-reading the control line every microsecond slow the ones that work)
+        if (spin < 4) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127);
     }
 }
 }  // namespace
@@ -1475,7 +1510,7 @@ __global__ void k_dag_rearm(DagParams D) {
             }
             D.slots[q][j] = v;
         }
-        if (i0 == 0) { D.ctl[q * kDagCtlStride] = 0; D.ctl[q * kDagCtlStride + 1] = ninit; }
+        if (i0 == 0) { D.ctl[q] = 0; D.ctl[kDagQueues + q] = ninit; D.ctl[kDagIdleCus] = 0; }
     }
     for (size_t j = i0 + kDagAbort; j < kDagCtlWords; j += stride) D.ctl[j] = 0;
 }
@@ -1497,13 +1532,15 @@ template <int WPS, bool AP, bool FOLD>
 __global__ __launch_bounds__(512, WPS) void k_bootstrap_dag(const DevParams* Pp, const DagParams* Dp) {
     extern __shared__ __align__(16) u32 smem[];
     // four words in front of the LDS layout of lat_bootstrap: [0] the item the workgroup runs next, [1] "first workgroup
-    // of its CU", [2] the CU's key
+    // of its CU", [2] the CU's key, [3] when the item was claimed
     u32* const mbox = smem;
     if (threadIdx.x == 0) {
         // which CU this workgroup sits on: HW_ID[15:8] = (SE, SH, CU), XCC_ID[3:0]
         const u32 hwid = __builtin_amdgcn_s_getreg((31u << 11) | 4u), xcc = __builtin_amdgcn_s_getreg((31u << 11) | 20u);
         const u32 key = ((xcc & 15u) << 8) | ((hwid >> 8) & 255u);
-        mbox[1] = dag_add(Dp->ctl + kDagCuArrive + key, 1u) != 1u;   // only a CU's second arrival yields
+        const u32 arrival = dag_add(Dp->ctl + kDagCuArrive + key, 1u);
+        if (arrival == 0) dag_add(Dp->ctl + kDagIdleCus, 1u);
+        mbox[1] = arrival == 0;   // the CU's first workgroup claims eagerly, later arrivals yield to idle CUs
         mbox[2] = key;
     }
     for (;;) {
@@ -1517,9 +1554,13 @@ __global__ __launch_bounds__(512, WPS) void k_bootstrap_dag(const DevParams* Pp,
         if (tid_a == 0) {
             ConstDagParams& D = *as_constant<ConstDagParams>(Dp);
             u32* const my_busy = D.ctl + kDagCuBusy + mbox[2];
+            const u64 t_in = __builtin_amdgcn_s_memrealtime();
             const u32 it = dag_acquire(D, my_busy, mbox[1] != 0);
             if (it != kDagExit) {
-                dag_add(my_busy, 1u);
+                const u64 t_got = __builtin_amdgcn_s_memrealtime();
+                __hip_atomic_fetch_add((__attribute__((address_space(1))) u64*)(D.ctl + kDagWaitTicks), t_got - t_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mbox[3] = (u32)t_got;
+                if (dag_add(my_busy, 1u) == 0) __hip_atomic_fetch_sub((gu32*)(D.ctl + kDagIdleCus), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1553,13 +1594,16 @@ __global__ __launch_bounds__(512, WPS) void k_bootstrap_dag(const DevParams* Pp,
                 const u32 c = D.cons[i];
                 if (__hip_atomic_fetch_sub((gu32*)(dep + c), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) {
                     const u32 q = D.qid[c];
-                    const u32 idx = dag_add(D.ctl + q * kDagCtlStride + 1, 1u);
+                    const u32 idx = dag_add(D.ctl + kDagQueues + q, 1u);
                     dag_st(D.slots[q] + idx, k * nt + c + 1u);
                 }
             }
             if (tid_p == 0) {
+                const u32 dt = (u32)__builtin_amdgcn_s_memrealtime() - mbox[3];
+                __hip_atomic_fetch_add((__attribute__((address_space(1))) u64*)(D.ctl + kDagBusyTicks), (u64)dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dag_add(D.ctl + kDagDone, 1u);
-                __hip_atomic_fetch_sub((gu32*)(D.ctl + kDagCuBusy + mbox[2]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_fetch_sub((gu32*)(D.ctl + kDagCuBusy + mbox[2]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
+                    dag_add(D.ctl + kDagIdleCus, 1u);
             }
         }
     }

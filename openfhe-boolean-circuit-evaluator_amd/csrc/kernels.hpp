@@ -73,12 +73,15 @@ size_t blind_rotate_lds_bytes(const DevParams& P);
 // bootstrap decrements its consumers' counters and pushes those that reach zero to a ready queue; idle workgroups pull
 // from the queues.  No kernel boundary and no device-wide barrier between dependent bootstraps.
 constexpr u32 kDagQueues = 4;        // priority classes (0 = most urgent)
-constexpr u32 kDagCtlStride = 32;    // u32 words per queue in the control block: [0] head, [1] tail (own 128-byte line)
+constexpr u32 kDagCtlStride = 32;    // control block: words [0, 4) = heads, [4, 8) = tails of the four classes (one 32-byte block)
 constexpr u32 kDagCuKeys = 4096;     // (XCC id, SE, SH, CU) keys of the placement table
-// control block (u32 words): queue q at q * kDagCtlStride; then the words below; then the per-CU tables
+// control block (u32 words): heads and tails in the first line; then the words below; then the per-CU tables
 constexpr u32 kDagAbort = kDagQueues * kDagCtlStride;      // != 0: a poller gave up (code)
 constexpr u32 kDagDone = kDagAbort + 1;                    // bootstraps completed
 constexpr u32 kDagLazyWaits = kDagAbort + 2;               // diagnostics: claims a half-busy CU delayed for an idle one
+constexpr u32 kDagBusyTicks = kDagAbort + 4;               // u64: 100 MHz ticks workgroups spent between claiming an item and releasing its consumers
+constexpr u32 kDagWaitTicks = kDagAbort + 6;               // u64: ticks workgroups spent looking for an item they then got
+constexpr u32 kDagIdleCus = 8;                             // compute units none of whose workgroups runs a bootstrap (same line as heads / tails)
 constexpr u32 kDagCuArrive = kDagAbort + 32;               // [kDagCuKeys] workgroups that announced themselves per CU
 constexpr u32 kDagCuBusy = kDagCuArrive + kDagCuKeys;      // [kDagCuKeys] workgroups running a bootstrap per CU
 constexpr u32 kDagCtlWords = kDagCuBusy + kDagCuKeys;
