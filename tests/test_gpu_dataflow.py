@@ -110,7 +110,7 @@ def test_dag_create_rejects_what_is_not_a_dag_in_ssa_form(bce, std):
         cc.dag_create([(bce.AND, 0, 1, 5)], prio=[7])
     dag = cc.dag_create([(bce.AND, 0, 1, 5)])
     with pytest.raises(bce.BceError):                      # instance 1 would leave the pool
-        cc.dag_run(dag, 2, 60, 0)
+        cc.dag_run(dag, 2, 1 << 30, 0)
     cc.dag_destroy(dag)
 
 
