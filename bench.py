@@ -3,8 +3,9 @@
 
 One "step" = one full encrypted evaluation (Circuit::Clock, verify off) of AES-expanded
 (old Bristol, 27,692 gates = 66,415 gate bootstraps) on K independent input blocks evaluated in
-lock-step per GPU (K = 32 by default); every ready frontier goes through bce_eval_gates_strided() to the HIP
-blind-rotation + key-switch kernels.  Keys, parsing and input encryption are outside the timed
+lock-step per GPU (K = 32 by default); every dependent step of the schedule goes through bce_eval_gates_strided() to the
+HIP blind-rotation + key-switch kernels (`--schedule dataflow`: the whole DAG through bce_dag_run, one persistent launch).
+`--config N` selects another BASELINE.json config (2 adder_64bit, 4 sha256, 5 AES-expanded STD192 AP) with the same line.  Keys, parsing and input encryption are outside the timed
 region (input ciphertexts are resident in HBM when timing starts).  Multi-GPU (`--gpus N`, one
 rank per GPU under torch.distributed.run): keys replicated from the same seed, instances sharded
 over ranks (weak scaling, K per GPU), RCCL used only to exchange the final outputs
@@ -54,33 +55,83 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """CPU restatement of the OpenFHE algorithm (oracle/, NOT OpenFHE itself) timed on this box's
-    host cores: independent STD128_OPT/GINX gate bootstraps, OpenMP across gates exactly like the
-    reference's task-per-gate loop (src/circuit.cpp:698-710).  Cost per bootstrap is data-independent."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def bristol_frontiers(path):
+    """old-format Bristol netlist -> the reference's Clock() rounds (src/circuit.cpp:575-683: a gate runs in the round
+    after its last input arrived; INV gates occupy rounds too), as lists of (op, in0, in1, out)."""
+    toks = [l.split() for l in open(path) if l.strip()]
+    n_in = int(toks[1][0]) + int(toks[1][1])
+    level = {w: 0 for w in range(n_in)}
+    rounds = []
+    for t in toks[2:]:
+        nin = int(t[0])
+        ins = [int(x) for x in t[2:2 + nin]]
+        out = int(t[2 + nin])
+        l = 1 + max(level[w] for w in ins)
+        level[out] = l
+        while len(rounds) < l:
+            rounds.append([])
+        rounds[l - 1].append((t[-1], ins[0], ins[-1], out))
+    return n_in, int(toks[0][1]), rounds
+
+
+def cpu_baseline(circuit_path, paramset, method, seconds_budget=20.0):
+    """the CPU restatement of the OpenFHE algorithm (oracle/, NOT OpenFHE itself) walks the REAL ready
+    frontiers of the benchmark circuit the way the reference does -- one OpenMP task per gate of a frontier
+    (src/circuit.cpp:698-710), XOR = NOT, NOT, AND, AND, OR (src/gate.cpp:198-202) -- on this box's host cores, for as
+    many rounds as fit the time budget."""
     from oracle import oracle as O
     cores = usable_cores()
-    o = O.Oracle(O.STD128_OPT, O.GINX)
+    o = O.Oracle(getattr(O, paramset), getattr(O, method))
     o.keygen(0x0FE5EED)
+    n_in, n_wires, rounds = bristol_frontiers(circuit_path)
+    max_x = max(sum(1 for g in r if g[0] == "XOR") for r in rounds)
     W = o.n + 1
-    # calibrate on one gate per core, then size the sample to the budget
-    def run(nb):
-        pool = np.zeros((3 * nb, W), dtype=np.uint64)
-        for i in range(2 * nb):
-            pool[i] = o.encrypt(i & 1, i)
-        descs = [(O.NAND, 2 * i, 2 * i + 1, 2 * nb + i, 0, 0) for i in range(nb)]
+    pool = np.zeros((n_wires + 2 * max_x, W), dtype=np.uint64)
+    rng = np.random.default_rng(99)
+    bits = {}
+    for w in range(n_in):
+        bits[w] = int(rng.integers(0, 2))
+        pool[w] = o.encrypt(bits[w], w)
+    boots, t_used, walked, checked = 0, 0.0, 0, 0
+    for r in rounds:
+        stage_a, stage_b = [], []
+        x = 0
+        for op, a, b, out in r:
+            if op == "AND":
+                stage_a.append((O.AND, a, b, out, 0, 0)); bits[out] = bits[a] & bits[b]
+            elif op == "XOR":
+                t1, t2 = n_wires + 2 * x, n_wires + 2 * x + 1
+                x += 1
+                stage_a += [(O.AND, a, b, t1, 0, 1), (O.AND, a, b, t2, 1, 0)]
+                stage_b.append((O.OR, t1, t2, out, 0, 0)); bits[out] = bits[a] ^ bits[b]
+            else:
+                stage_a.append((O.OP_NOT, a, a, out, 0, 0)); bits[out] = 1 - bits[a]
         t0 = time.time()
-        done = o.eval_gates(pool, descs, nthreads=cores)
-        dt = time.time() - t0
-        assert done == nb
-        assert all(o.decrypt(pool[2 * nb + i]) == 1 - ((2 * i) & 1 & ((2 * i + 1) & 1)) for i in range(0, nb, max(1, nb // 8)))
-        return dt
-    t1 = run(cores)
-    nb = int(max(cores, min(64 * cores, cores * max(1.0, (seconds_budget / 2) / max(t1, 1e-3)))))
-    dt = run(nb)
-    return {"value": nb / dt, "unit": "gate-bootstraps/s", "cores": cores, "kind": "port",
-            "sample": "%d independent STD128_OPT/GINX NAND gate bootstraps (same per-gate work as every AES gate), "
-                      "OpenMP over gates on %d threads, %.1f s; CPU restatement of the OpenFHE algorithm, not OpenFHE" % (nb, cores, dt)}
+        for st in (stage_a, stage_b):
+            if st:
+                boots += o.eval_gates(pool, st, nthreads=cores)
+        t_used += time.time() - t0
+        walked += 1
+        for op, a, b, out in r[:: max(1, len(r) // 4)]:
+            assert o.decrypt(pool[out]) == bits[out], "CPU baseline: gate output decrypts wrongly"
+            checked += 1
+        if t_used >= seconds_budget:
+            break
+    return {"value": boots / t_used, "unit": "gate-bootstraps/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
+            "sample": "the first %d of %d ready-gate rounds of %s (%d gate-bootstraps, %s %s; XOR = 3 bootstraps), one OpenMP task per "
+                      "gate of a round on %d threads as src/circuit.cpp:698-710 does, %.1f s, %d outputs decrypted and checked; "
+                      "CPU restatement of the OpenFHE algorithm, not OpenFHE" % (
+                          walked, len(rounds), os.path.basename(circuit_path), boots, paramset, method, cores, t_used, checked)}
 
 
 def spawn_ranks(n, argv):
@@ -118,6 +169,13 @@ def main():
     ap.add_argument("--instances", type=int, default=32, help="AES blocks evaluated in lock-step per GPU")
     ap.add_argument("--circuit", default="AES-expanded.txt")
     ap.add_argument("--paramset", default="STD128_OPT")
+    ap.add_argument("--method", choices=["GINX", "AP"], default="GINX")
+    ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=None,
+                    help="a BASELINE.json config by number: 2 adder_64bit (K = 256), 3 the headline (default), 4 sha256 (K = 16), "
+                         "5 AES-expanded STD192 AP (K = 8); explicit --circuit / --paramset / --method / --instances win over it")
+    ap.add_argument("--schedule", choices=["steps", "dataflow"], default="steps",
+                    help="steps: one launch per dependent step of the bootstrap-depth schedule (default); dataflow: the whole "
+                         "bootstrap DAG in one persistent launch with device-side ready queues (bce_dag_*)")
     ap.add_argument("--shard", choices=["instances", "gates"], default="instances")
     ap.add_argument("--no-relevel", dest="relevel", action="store_false",
                     help="schedule by gate level exactly like the reference's Clock() rounds (496 launches for AES) instead of "
@@ -131,6 +189,14 @@ def main():
     ap.add_argument("--gates-timeout", type=int, default=150, help="N > 1: watchdog (s) over the secondary run and the teardown")
     ap.add_argument("--gates-steps", type=int, default=2, help="N > 1: timed steps of the secondary gate-sharded run (0 = skip)")
     args = ap.parse_args()
+    if args.config is not None:
+        preset = {2: ("adder_64bit.txt", "STD128_OPT", "GINX", 256), 3: ("AES-expanded.txt", "STD128_OPT", "GINX", 32),
+                  4: ("sha256_new.txt", "STD128_OPT", "GINX", 16), 5: ("AES-expanded.txt", "STD192", "AP", 8)}[args.config]
+        given = " ".join(sys.argv[1:])
+        if "--circuit" not in given: args.circuit = preset[0]
+        if "--paramset" not in given: args.paramset = preset[1]
+        if "--method" not in given: args.method = preset[2]
+        if "--instances" not in given: args.instances = preset[3]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus, sys.argv[1:])      # does not return
@@ -169,14 +235,14 @@ def main():
 
     # ---- setup (untimed): context, keys (same seed on every rank = replicated), circuit, inputs
     t_setup = time.time()
-    cc = bce.BinFHEContext(getattr(bce, args.paramset), bce.GINX, device=local_rank)
+    cc = bce.BinFHEContext(getattr(bce, args.paramset), getattr(bce, args.method), device=local_rank)
     t_kg = time.time()
     cc.KeyGen(0x0FE5EED)            # explicit seed: the SAME key set on every rank (synthetic benchmark keys)
     keygen_s = time.time() - t_kg
     path = os.path.join(ROOT, "tests", "golden", "circuits", args.circuit)
     K_total = args.instances
 
-    def run_mode(shard_mode, steps, warmup, relevel):
+    def run_mode(shard_mode, steps, warmup, relevel, exchange="callback"):
         """One timed run.  shard_mode 0 (instances): every rank evaluates ITS OWN K input blocks with its own
         circuit object -- independent units, no data-path collective (only the barrier / reductions of this
         script).  shard_mode 1 (gates): ONE set of K blocks, every level's gates split over the ranks by bootstrap
@@ -190,6 +256,8 @@ def main():
             cc.set_encrypt_seed(0x0FE5EED)   # every rank must encrypt IDENTICAL input ciphertexts
         if relevel:
             circ.setRelevel(True)
+        if args.schedule == "dataflow" and not gates:
+            circ.setDataflow(True)
         info = circ.info()
         circ.setInstances(K_total)
         xch = None
@@ -198,7 +266,7 @@ def main():
             # (falls back, on every rank together, to the torch.distributed callback if RCCL cannot be initialised)
             xch = importlib.import_module("openfhe-boolean-circuit-evaluator_amd.dist").Exchange(
                 circ, 1, encrypted=True, device=torch.device("cuda", local_rank),
-                in_library=(backend == "nccl" and os.environ.get("BCE_EXCHANGE", "rccl") == "rccl"))
+                in_library=(backend == "nccl" and exchange == "rccl"))
         rng = np.random.default_rng(12345 + (0 if gates else rank))
         widths = info["n_input_bits"]
         inputs = []
@@ -221,6 +289,17 @@ def main():
             circ.SetInput(inputs[k], instance=k)
         cc.synchronize()
         t_ready = time.time()
+        df_active = circ.dataflowActive()
+        xmod = importlib.import_module("openfhe-boolean-circuit-evaluator_amd.dist") if gates else None
+        k_ident = min(2, K_total)
+        if gates:
+            # ciphertext identity below compares the registers this rank holds after the run with a single-rank evaluation:
+            # start from zeros, so that "holds" is readable from the pool (the pool may carry an earlier run's registers)
+            regs, _ = xmod.gate_registers(path, args.circuit.startswith("sha256_new"))
+            stride0 = circ.info()["slot_stride"]
+            zeros = np.zeros((len(regs), cc.n + 1), dtype=np.uint64)
+            for k in range(k_ident):
+                cc.lwe_write(np.array(regs, dtype=np.uint32) + k * stride0, zeros)
 
         def step():
             circ.Rearm()
@@ -257,10 +336,28 @@ def main():
             xcts = float(t[3])
         else:
             xcts = 0.0
+        identity = None
         if gates:
+            # every bootstrapped register this rank computed or received == the un-sharded evaluation of the same input
+            # ciphertexts, bit for bit (first instances; replicated keys make the bootstraps deterministic)
+            try:
+                held, same, per_inst = xmod.check_against_single_rank(cc, circ, path, args.circuit.startswith("sha256_new"), relevel, k_ident)
+                ident_ok = held == same
+            except AssertionError as e:
+                held, same, per_inst, ident_ok = -1, -1, -1, False
+                sys.stderr.write("bench.py: rank %d: %s\n" % (rank, e))
+            t = torch.tensor([float(held), 0.0 if ident_ok else 1.0], dtype=torch.float64, device=red_dev)
+            tmx = t.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+            identity = {"instances_checked": k_ident, "bootstrapped_registers_per_instance": per_inst,
+                        "registers_held_over_all_ranks": int(t[0]), "identical_to_single_rank_evaluation": bool(float(tmx[1]) == 0.0)}
+            verified = verified and identity["identical_to_single_rank_evaluation"]
             cc.set_encrypt_seed(None)
         circ.close()
         return {"elapsed": elapsed, "total_boot": total_boot, "verified": verified, "tm": tm, "info": info, "relevel": relevel,
+                "launches_per_step": st["sublaunches"], "dataflow": df_active, "identity": identity,
+                "dag_last_run": cc.dag_last_run() if (args.schedule == "dataflow" and not gates) else None,
                 "exchanges_per_step": st["exchanges"], "exchanged_cts_per_step": xcts, "steps": steps, "t_ready": t_ready,
                 "exchange_path": ("in-library ncclAllGather on the engine stream (no host sync)" if (xch is not None and xch.in_library) else
                                   ("torch.distributed all_gather_into_tensor callback after a stream sync" + (" [in-library RCCL unavailable: %s]" % xch.why if xch is not None and xch.why not in ("", "not requested") else "")) if xch is not None else "none")}
@@ -287,7 +384,7 @@ def main():
         c1.close()
         return dt
     block_latency_s = None if args.no_block_latency else single_block_latency()
-    G = G_err = None
+    G = G_err = G2 = G2_err = None
     out = None
     elapsed, total_boot, verified, tm, info = R["elapsed"], R["total_boot"], R["verified"], R["tm"], R["info"]
 
@@ -297,72 +394,101 @@ def main():
         except Exception:
             return None
 
-    default_cmd = (args.instances == 32 and args.circuit == "AES-expanded.txt" and args.paramset == "STD128_OPT"
-                   and shard_mode == 0 and R["relevel"] and not args.xor_fast)
+    default_cmd = (args.instances == 32 and args.circuit == "AES-expanded.txt" and args.paramset == "STD128_OPT" and args.method == "GINX"
+                   and shard_mode == 0 and R["relevel"] and not args.xor_fast and args.schedule == "steps")
     if rank == 0:
         parts = cc.bytes_per_bootstrap_parts()         # {"bsk", "ksk", "ct"} at this build's widths (SURVEY 8(d) formula)
         bpb = parts["bsk"] + parts["ksk"] + parts["ct"]
         pr = cc.params
-        bsk_once = 4 * pr["n"] * 2 * (2 * pr["dG"]) * 2 * pr["N"]   # u32 GINX key, read once if perfectly shared
-        # roofline of the DOMINANT blind-rotation kernel of this run (launch size picks between kernels)
+        ginx = args.method == "GINX"
+        # the key read ONCE (what a launch must move if every bootstrap of it shared the key perfectly); AP bootstraps
+        # walk digit-selected keys of their own, so nothing is shared by construction there
+        bsk_once = (cc.bsk_word_bytes() * pr["n"] * 2 * (2 * pr["dG"]) * 2 * pr["N"]) if ginx else None
+        # the DOMINANT blind-rotation kernel of this run (launch size and schedule pick between kernels)
         dom = max(tm["by_kernel"], key=lambda k: k["ms"])
         br_s = dom["ms"] / 1e3
         per_launch = dom["bootstraps"] / max(1, dom["launches"])
         avg_launch_ms = dom["ms"] / max(1, dom["launches"])
-        # saturated launches of the split-transform kernel run the tail (KSK row gather) in their epilogue: the KSK rows are
-        # then bytes of the blind-rotation kernel, and no tail kernel exists
+        # saturated launches of the split-transform kernel (and the persistent kernel) run the tail (KSK row gather) in their
+        # epilogue: the KSK rows are then bytes of the blind-rotation kernel, and no tail kernel exists
         fused = tm["fused_tail_launches"] >= tm["blind_rotate_launches"] > 0
         br_bytes = parts["bsk"] + parts["ct"] + (parts["ksk"] if fused else 0)   # what the dominant kernel itself moves per bootstrap
         achieved = (br_bytes * dom["bootstraps"] / br_s) / 1e9 if br_s > 0 else 0.0
         tail_s = tm["tail_ms"] / 1e3
         tail_achieved = (parts["ksk"] * tm["bootstraps"] / tail_s) / 1e9 if tail_s > 0 else 0.0
-        # committed PMC passes of this same default command / of one saturated launch of this kernel
-        # (rocprofv3 cannot run inside the timed region: these are REPLAYED constants, named with their files)
-        traffic = load_profile("r02_pmc_traffic.json") if default_cmd else None
-        valu = load_profile("r02_valu_model.json")
-        roof = {
-            "bound": "hbm", "kernel": dom["kernel"],
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic["hbm_bytes_per_launch"] if traffic and traffic.get("bench_kernel") == dom["kernel"] else None,
-            "traffic_source": "profiles/r02_pmc_traffic.json: bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of "
-                              "this default command, tools/collect_evidence.sh) -- a committed constant replayed here, NOT measured in this run",
-            "bytes_per_bootstrap": {"bsk_rows_u32": parts["bsk"], "ct_io_u32": parts["ct"], "ksk_rows_u16": parts["ksk"], "total": bpb,
+        # committed PMC passes of this same command / of one saturated launch of this kernel (rocprofv3 cannot run inside
+        # the timed region: REPLAYED constants, named with their files; the newest round's files first)
+        def newest(names):
+            for n in names:
+                d = load_profile(n)
+                if d is not None:
+                    return d, n
+            return None, None
+        cfg5 = args.paramset == "STD192" and args.method == "AP"
+        traffic, traffic_file = newest(["r03_pmc_traffic.json", "r02_pmc_traffic.json"]) if default_cmd else (None, None)
+        valu, valu_file = newest(["r03_valu_model.json", "r02_valu_model.json"]) if not cfg5 else newest(["r03_cfg5_roofline.json", "r02_cfg5_roofline.json"])
+        traffic_bytes = traffic["hbm_bytes_per_launch"] if traffic and traffic.get("bench_kernel") == dom["kernel"] else None
+        compulsory = (bsk_once + (parts["ct"] + (parts["ksk"] if fused else 0)) * per_launch) if bsk_once is not None else br_bytes * per_launch
+        hbm = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "what": "the task's convention: ALGORITHMIC bytes of this kernel per bootstrap (SURVEY 8(d) formula at this build's widths) x "
+                    "bootstraps / its time by HIP events on the engine stream",
+            "bytes_per_bootstrap": {"bsk_rows": parts["bsk"], "ct_io": parts["ct"], "ksk_rows": parts["ksk"], "total": bpb,
                                     "billed_to_this_kernel": br_bytes, "tail_fused_into_this_kernel": bool(fused)},
             "algorithmic_bytes_per_launch": br_bytes * per_launch,
-            # the key is reused from cache across a batch, so also the compulsory bytes of a launch:
-            # the key once + per-bootstrap ciphertext / accumulator I/O
-            "compulsory_bytes_per_launch": bsk_once + (parts["ct"] + (parts["ksk"] if fused else 0)) * per_launch,
-            "bootstraps_per_launch": per_launch,
-            "avg_launch_ms": avg_launch_ms,
-            "launches": dom["launches"],
-            "share_of_blind_rotation_time": dom["ms"] / max(1e-9, tm["blind_rotate_ms"]),
-            "other_blind_rotation_kernels": [k for k in tm["by_kernel"] if k is not dom and k["launches"]],
-            "tail": ({"kernel": "none: extract + ModSwitch + KeySwitch + ModSwitch run in the epilogue of the blind-rotation kernel (fused_tail)",
-                      "ms_total": tm["tail_ms"]} if fused else
-                     {"kernel": "k_tail_gather + k_tail_finish", "bound": "hbm", "ms_total": tm["tail_ms"],
-                      "avg_launch_ms": tm["tail_ms"] / max(1, tm["blind_rotate_launches"]),
-                      "achieved": tail_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tail_achieved / HBM_PEAK_GBS,
-                      "traffic": (traffic or {}).get("tail_hbm_bytes_per_launch"),
-                      "note": "KSK row gather: algorithmic = N*dKS rows of (n+1) u16 per bootstrap; rows come from the 256 MiB table "
-                              "(Infinity-Cache sized), so the fabric counters see them"}),
-            "note": "achieved = algorithmic bytes of the blind-rotation kernel (u32 BSK rows + ct I/O + the KSK rows of its fused tail, per bootstrap) x bootstraps / its "
-                    "time from HIP events on the engine stream.  The 62.8 MiB key is served from L2 / Infinity Cache across the "
-                    "batch (compulsory << algorithmic), so this fraction can exceed 1 and does not bind; the binding roof is "
-                    "integer-VALU issue: see `valu`",
+            "compulsory_bytes_per_launch": compulsory,
+            "counter_traffic_bytes_per_launch": traffic_bytes,
+            "counter_traffic_frac_of_peak": (traffic_bytes / (avg_launch_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if traffic_bytes else None,
+            "wasted_traffic_ratio": (traffic_bytes / compulsory) if traffic_bytes else None,
+            "traffic_source": ("profiles/%s: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this default command "
+                               "(tools/collect_evidence.sh) -- a committed constant replayed here, NOT measured in this run" % traffic_file) if traffic_bytes else None,
         }
-        if valu and valu.get("bench_kernel") == dom["kernel"]:
-            # VALU roof: wave-instructions per bootstrap (SQ_INSTS_VALU of one saturated launch, committed PMC pass) x the
-            # measured issue cost per wave-instruction per SIMD of this kernel's instruction mix (tools/valu_rates.hip,
-            # tools/valu_model.py) / SIMDs of the chip = the time the launch needs at 100 % VALU issue
+        roof = dict(hbm)
+        roof.update({"kernel": dom["kernel"], "traffic": traffic_bytes, "bootstraps_per_launch": per_launch, "avg_launch_ms": avg_launch_ms,
+                     "launches": dom["launches"], "share_of_blind_rotation_time": dom["ms"] / max(1e-9, tm["blind_rotate_ms"]),
+                     "other_blind_rotation_kernels": [k for k in tm["by_kernel"] if k is not dom and k["launches"]],
+                     "tail": ({"kernel": "none: extract + ModSwitch + KeySwitch + ModSwitch run in the epilogue of the blind-rotation kernel (fused_tail)",
+                               "ms_total": tm["tail_ms"]} if fused else
+                              {"kernel": "k_tail_gather + k_tail_finish", "bound": "hbm", "ms_total": tm["tail_ms"],
+                               "avg_launch_ms": tm["tail_ms"] / max(1, tm["blind_rotate_launches"]),
+                               "achieved": tail_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tail_achieved / HBM_PEAK_GBS,
+                               "note": "KSK row gather: algorithmic = N*dKS rows of (n+1) words per bootstrap"})})
+        # The roof that BINDS goes on top.  32-bit path (GINX, Q < 2^28): the key is served from L2 / Infinity Cache across the
+        # batch, the HBM convention exceeds 1 and says nothing; the kernel is bound by integer-VALU issue.  64-bit AP path
+        # (config 5): the digit-selected keys are hardly shared, HBM binds first by the convention and fp64 issue is next.
+        vm = None
+        if valu and not cfg5 and valu.get("bench_kernel") == dom["kernel"]:
             simds = 4 * (valu.get("cu_count") or 256)
-            floor_ms = valu["valu_insts_per_bootstrap"] * per_launch * valu["ns_per_wave_inst_per_simd"] / simds / 1e6
-            roof["valu"] = {"bound": "integer VALU issue", "insts_per_bootstrap": valu["valu_insts_per_bootstrap"],
-                            "ns_per_wave_inst_per_simd": valu["ns_per_wave_inst_per_simd"], "simds": simds,
-                            "floor_ms_per_launch": floor_ms, "avg_launch_ms": avg_launch_ms, "frac": floor_ms / avg_launch_ms if avg_launch_ms else None,
-                            "source": "profiles/r02_valu_model.json (SQ_INSTS_VALU pass + instruction mix of the ISA + measured issue "
-                                      "costs; committed constants, the launch time is this run's)"}
-            roof["frac_valu"] = roof["valu"]["frac"]
-            roof["binding"] = {"roof": "integer VALU issue (see `valu`); the HBM fraction above prices bytes the caches serve", "frac": roof["valu"]["frac"]}
+            vm = {"insts_per_bootstrap": valu["valu_insts_per_bootstrap"], "ns_per_wave_inst_per_simd": valu["ns_per_wave_inst_per_simd"], "simds": simds}
+            vm_src = "profiles/%s (SQ_INSTS_VALU of one saturated launch + instruction mix of the ISA + measured issue cost per opcode; committed constants, the launch time is this run's)" % valu_file
+        elif valu and cfg5 and "valu" in valu:
+            vm = {"insts_per_bootstrap": valu["valu"]["insts_per_bootstrap"], "ns_per_wave_inst_per_simd": valu["valu"]["ns_per_wave_inst_per_simd"], "simds": 1024}
+            vm_src = "profiles/%s (SQ_INSTS_VALU + fp64 issue cost of the step loop's mix; committed constants, the launch time is this run's)" % valu_file
+        if vm:
+            peak_ginst = vm["simds"] / vm["ns_per_wave_inst_per_simd"]                                  # G wave-instructions / s the chip can issue
+            ach_ginst = vm["insts_per_bootstrap"] * dom["bootstraps"] / br_s / 1e9 if br_s > 0 else 0.0
+            valu_obj = {"bound": "valu", "what": ("integer" if not cfg5 else "fp64") + " VALU issue: wave-instructions the kernel executes per second against what "
+                        "the chip's %d SIMDs can issue for this kernel's instruction mix" % vm["simds"],
+                        "achieved": ach_ginst, "peak": peak_ginst, "unit": "G wave-inst/s", "frac": ach_ginst / peak_ginst,
+                        "insts_per_bootstrap": vm["insts_per_bootstrap"], "ns_per_wave_inst_per_simd": vm["ns_per_wave_inst_per_simd"],
+                        "floor_ms_per_launch": vm["insts_per_bootstrap"] * per_launch * vm["ns_per_wave_inst_per_simd"] / vm["simds"] / 1e6,
+                        "source": vm_src}
+            if not cfg5:
+                # binding roof on top, the HBM figures below it
+                for k in ("bound", "what", "achieved", "peak", "unit", "frac"):
+                    roof[k] = valu_obj[k]
+                roof["valu"] = valu_obj
+                roof["hbm"] = hbm
+                for k in ("bytes_per_bootstrap", "algorithmic_bytes_per_launch", "compulsory_bytes_per_launch", "counter_traffic_bytes_per_launch",
+                          "counter_traffic_frac_of_peak", "wasted_traffic_ratio", "traffic_source"):
+                    roof.pop(k, None)
+                roof["note"] = ("bound = integer-VALU issue (what limits this kernel); `hbm` keeps the byte convention (frac > 1: the 62.8 MiB key is "
+                                "served from L2 / Infinity Cache across the batch), the counter-based traffic and the wasted-traffic ratio")
+            else:
+                roof["valu"] = valu_obj
+                roof["note"] = "bound = HBM by the byte convention (AP keys are digit-selected per bootstrap and hardly shared); `valu` = fp64 issue, the next roof"
+        if R["dataflow"]:
+            roof["dataflow"] = R["dag_last_run"]
         out = {
             "metric": METRIC,
             "value": total_boot / elapsed,
@@ -374,21 +500,26 @@ def main():
             "higher_is_better": True,
             "scaling": "weak" if shard_mode == 0 else "strong",
             "vs_baseline": None,
-            "dtype": "u32",
+            "dtype": "u32" if not cc.is64() else ("f64 (exact integers < 2^53 in IEEE doubles)" if cc.fp64() else "u64"),
             "data": "synthetic",
             "config": {
-                "workload": "%s (%d gates, %d gate-bootstraps/eval, %d dependent sub-launches) %s GINX, "
+                "workload": "%s (%d gates, %d gate-bootstraps/eval; %d kernel launches per evaluation as run) %s %s, "
                             "%d input blocks in lock-step per GPU, verify off" % (
                                 args.circuit, info["n_gates"] - info["n_output_bits"], info["n_bootstraps"],
-                                info["n_sublaunches"], args.paramset, args.instances),
+                                R["launches_per_step"], args.paramset, args.method, args.instances),
+                "baseline_config": args.config if args.config is not None else (3 if default_cmd else None),
                 "instances_per_gpu": args.instances, "sharding": args.shard,
-                "schedule": "bootstrap-depth levels (NOTs folded, steps filled by slack up to the launch staircase, identical ciphertexts)" if R["relevel"] else "gate levels (reference Clock rounds)",
+                "schedule": ("dataflow: the whole bootstrap DAG in one persistent launch, device-side ready queues (identical ciphertexts)" if R["dataflow"] else
+                             "bootstrap-depth levels (NOTs folded, steps filled by slack up to the launch staircase, identical ciphertexts)" if R["relevel"] else "gate levels (reference Clock rounds)"),
+                "launches_per_step": R["launches_per_step"],
+                "reference_clock_rounds": info["n_levels"], "reference_sub_launches": info["n_sublaunches"],
                 "xor": "XOR_FAST (opt-in, 1 bootstrap)" if args.xor_fast else "NOT,NOT,AND,AND,OR (reference, 3 bootstraps)",
                 "bootstraps_per_step": int(total_boot / args.steps),
                 "forward_transforms_per_blind_rotation_step": cc.forward_transforms_per_step(),
                 "gates_per_s": (info["n_gates"] - info["n_output_bits"]) * args.instances * world * args.steps / elapsed,
                 "single_block_latency_s": None if block_latency_s is None else round(block_latency_s, 4),
                 "outputs_verified": bool(verified), "setup_s": round(setup_s, 2), "keygen_s": round(keygen_s, 3),
+                "input_encryption": "cc.Encrypt default of OpenFHE v1.0.x: BOOTSTRAPPED (one refresh bootstrap per input bit, %d per block, inside setup_s, outside the timed region)" % info["n_input_gates"],
                 "host_share_of_step": round(1.0 - (tm["blind_rotate_ms"] + tm["tail_ms"]) / (elapsed * 1e3), 4),
                 "exchanges_per_step": R["exchanges_per_step"], "exchanged_cts_per_step": R["exchanged_cts_per_step"],
                 "collective": "none in the timed region (independent input blocks per rank)" if shard_mode == 0 else
@@ -417,7 +548,9 @@ def main():
                 emit()
             sys.stderr.write("bench.py: rank %d watchdog fired after %d s\n" % (rank, args.gates_timeout))
             sys.stderr.flush()
-            os._exit(0 if verified else 2)
+            # a process that has touched the GPU and hangs in a collective is a FAILURE of the run: the headline line is out,
+            # the exit code says so (the parent prints "ranks failed"); no restart, no re-exec
+            os._exit(3)
 
     wd = None
     if world > 1:
@@ -428,9 +561,17 @@ def main():
         try:        # a failure of the secondary run must not cost the headline line
             if os.environ.get("BCE_BENCH_TEST_HANG") == "1" and rank == world - 1:
                 time.sleep(1e6)      # test hook (tests/test_bench_launch.py): one rank never reaches the collective
-            G = run_mode(1, args.gates_steps, 1, args.relevel)
+            G = run_mode(1, args.gates_steps, 1, args.relevel, exchange=os.environ.get("BCE_EXCHANGE", "callback"))
         except Exception as e:
             G_err = repr(e)
+        # the library's own RCCL all-gather on the engine stream has never run between two devices (no multi-GPU node was
+        # available to the builder): the verified torch.distributed callback carries the leg above, and this short extra
+        # leg puts the in-library path on record whenever a node is there (outputs verified like every other run)
+        if G is not None and backend == "nccl" and os.environ.get("BCE_EXCHANGE", "callback") != "rccl":
+            try:
+                G2 = run_mode(1, 1, 1, args.relevel, exchange="rccl")
+            except Exception as e:
+                G2_err = repr(e)
     if rank == 0:
         if G_err is not None:
             out["shard_gates"] = {"error": G_err}
@@ -445,11 +586,24 @@ def main():
                 "exchanges_per_step": G["exchanges_per_step"], "exchanged_cts_per_step": G["exchanged_cts_per_step"],
                 "exchange_path": G["exchange_path"],
                 "outputs_verified": bool(G["verified"]),
+                "ciphertext_identity": G["identity"],
             }
+            try:   # what the host-side model expects of this partition on 1, 2, 4, 8 GPUs (a prediction to check SCALE runs against)
+                pred = importlib.import_module("openfhe-boolean-circuit-evaluator_amd.predict")
+                if args.paramset in ("STD128_OPT", "STD128") and G["relevel"]:
+                    out["shard_gates"]["predicted"] = pred.predict_gate_sharding(path, args.circuit.startswith("sha256_new"), args.instances)
+            except Exception as e:
+                out["shard_gates"]["predicted"] = {"error": repr(e)}
             if not G["verified"]:      # reported where it belongs; the headline run has its own flag (config.outputs_verified)
                 out["shard_gates"]["error"] = "decrypted outputs differ from the plaintext evaluation"
+        if G2 is not None or G2_err is not None:
+            out["shard_gates_in_library_rccl"] = ({"error": G2_err} if G2 is None else {
+                "what": "the same gate-sharded run with the exchange as ncclAllGather issued by the library on the engine stream (no host sync)",
+                "value": G2["total_boot"] / G2["elapsed"], "unit": "gate-bootstraps/s", "ms_per_step": G2["elapsed"] / G2["steps"] * 1e3,
+                "steps": G2["steps"], "exchange_path": G2["exchange_path"], "outputs_verified": bool(G2["verified"]),
+                "ciphertext_identity": G2["identity"]})
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(path, args.paramset, args.method, args.cpu_seconds)
         with emit_lock:
             emit()
     if dist is not None:

@@ -80,8 +80,12 @@ int bce_circuit_get_flags(const bce_circuit*, int* plaintext, int* encrypted, in
 /* 0: one bce_eval_gates call per gate through Gate::Evaluate (reference shape);
  * 1 (default): one call per frontier stage */
 int bce_circuit_set_batched(bce_circuit*, int on);
-/* BinFHEContext::Encrypt output mode used by SetInput: BCE_FRESH (default) or BCE_BOOTSTRAPPED */
+/* Output mode of cc.Encrypt(sk, bit) as SetInput (src/circuit.cpp:506) and the verify-mode repairs
+ * (src/gate.cpp:118,139,143,158,179,211) call it.  Default BCE_BOOTSTRAPPED: OpenFHE v1.0.x's Encrypt defaults to
+ * BOOTSTRAPPED, i.e. every fresh ciphertext goes through one Bootstrap (one extra gate-bootstrap per input bit, run as
+ * one batched launch per SetInput call here; not counted in the Clock() statistics).  BCE_FRESH skips it. */
 int bce_circuit_set_encrypt_mode(bce_circuit*, int mode);
+int bce_circuit_get_encrypt_mode(const bce_circuit*);
 
 /* opt-in extension, NOT reference semantics: evaluate XOR gates natively with OpenFHE's XOR_FAST
  * (one bootstrap of 2*(ct1-ct2) instead of NOT,NOT,AND,AND,OR); the reference keeps this disabled
@@ -115,6 +119,10 @@ int bce_circuit_check_relevel(bce_circuit*);
  * sharding and for parameter classes without the persistent kernel: bce_circuit_dataflow_active tells. */
 int bce_circuit_set_dataflow(bce_circuit*, int on);
 int bce_circuit_dataflow_active(const bce_circuit*);   /* 1 if the next encrypted Clock() takes the dataflow path */
+/* The task list of the dataflow schedule (what bce_dag_create receives): gates in topological order with SSA slots for
+ * ONE instance (slot < slot_stride of bce_circuit_get_info) and their priority classes.  Writes min(*n_tasks, cap)
+ * entries to each non-NULL array and sets *n_tasks to the number of tasks (= bootstraps of one evaluation). */
+int bce_circuit_dataflow_plan(const bce_circuit*, bce_gate_desc* tasks, uint8_t* prio, uint32_t cap, uint32_t* n_tasks);
 /* K independent input sets evaluated in lock-step (call before SetInput) */
 int bce_circuit_set_instances(bce_circuit*, uint32_t k);
 /* Circuit::SetInput, src/circuit.cpp:455-530: bits = concatenation of the input buses,
@@ -150,6 +158,14 @@ int bce_circuit_set_exchange(bce_circuit*, uint32_t rank, uint32_t world, int sh
  * instead of the callback -- no host synchronisation and no callback per level.  Host payloads (plaintext bits,
  * final outputs) keep using the callback.  on = 0 returns to the callback for everything. */
 int bce_circuit_enable_rccl(bce_circuit*, int on);
+/* Gate sharding on the bootstrap-depth schedule: 1 (default) places a unit on the rank that produced most of its inputs,
+ * within each rank's fair share of the step (fewer ciphertexts cross ranks); 0 = contiguous split in netlist
+ * order.  Every rank must use the same setting (bce_circuit_plan_hash covers it). */
+int bce_circuit_set_shard_locality(bce_circuit*, int on);
+/* Digest of what the ranks of a sharded run must agree on (gate owners, publications per step, slot stride, instance
+ * count).  The plans are built independently on every rank from the device's launch capacity; compare the digests
+ * across ranks (dist.Exchange does) before the first Clock(): different plans mean exchanges of different sizes. */
+uint64_t bce_circuit_plan_hash(const bce_circuit*);
 /* bytes one rank may contribute in the largest exchange of this circuit/instance count */
 uint64_t bce_circuit_exchange_capacity(const bce_circuit*, uint32_t world, int shard_mode, int encrypted);
 

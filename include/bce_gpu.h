@@ -114,6 +114,14 @@ int bce_keygen(bce_ctx*, const uint8_t seed[32]);
  * (GINX) or [i][v][k][row][col][N] (AP); ksk [i][v][j][n+1] mod qKS. */
 int bce_import_keys(bce_ctx*, const int32_t* s, const int32_t* z, const uint64_t* bsk, uint64_t bsk_words,
                     const uint32_t* ksk, uint64_t ksk_words);
+/* Same, with the bootstrapping key already in EVALUATION form as OpenFHE holds it after BTKeyGen: every polynomial in
+ * the bit-reversed order of OpenFHE's Cooley-Tukey forward transform (transformnat-impl.h) for psi = the minimal
+ * primitive 2N-th root of unity mod Q (bce_get_params: BCE_P_psi; 455622 / 341565 / 13167220 for the tabulated sets) --
+ * the engine's own order, so an OpenFHE-side dump needs no SetFormat(COEFFICIENT) pass over the key (12.9 GB for
+ * STD192 / AP) and the import needs no transform.  bce_export_bsk_eval is its inverse. */
+int bce_import_keys_eval(bce_ctx*, const int32_t* s, const int32_t* z, const uint64_t* bsk_eval, uint64_t bsk_words,
+                         const uint32_t* ksk, uint64_t ksk_words);
+int bce_export_bsk_eval(bce_ctx*, uint64_t* bsk_eval);
 /* The same material from / to a file in the format of tools/openfhe_export/bce_keyfile.h -- what the
  * OpenFHE-side exporter (tools/openfhe_export/export_keys.cpp) writes for the keys of an existing deployment
  * (cc.KeyGen() / cc.BTKeyGen(sk), src/circuit.cpp:90-91).  Parameters in the file must match the context. */
@@ -224,6 +232,9 @@ int bce_launch_capacity(const bce_ctx*, uint32_t* lone, uint32_t* full);
  * it).  RCCL is dlopen()ed on first use.  Rendezvous: rank 0 calls bce_rccl_unique_id and the host program
  * delivers the 128 bytes to every rank, each of which then calls bce_rccl_init with its rank. */
 int bce_rccl_available(void);   /* 1 when the RCCL library and the entry points used here could be loaded */
+int bce_rccl_version(void);     /* ncclGetVersion of that library (2.x ABI required), 0 if none.  NOTE: between two or more
+                                 * devices this path has not run on hardware yet (no multi-GPU node was available to the
+                                 * builder); the torch.distributed callback of bce_circuit_set_exchange is the verified one. */
 int bce_rccl_unique_id(uint8_t out[128]);
 int bce_rccl_init(bce_ctx*, const uint8_t uid[128], int rank, int world);
 /* every rank contributes `bytes` bytes at dev_send and receives world * bytes at dev_recv, rank-major; asynchronous,

@@ -56,10 +56,10 @@ class Timing(C.Structure):
 
 ENGINE_SYMBOLS = [
     "bce_ctx_create", "bce_ctx_create_custom", "bce_ctx_destroy", "bce_last_error", "bce_get_params",
-    "bce_keygen", "bce_import_keys", "bce_import_keys_file", "bce_export_keys_file", "bce_bsk_words", "bce_ksk_words", "bce_export_sk", "bce_export_bsk",
+    "bce_keygen", "bce_import_keys", "bce_import_keys_eval", "bce_export_bsk_eval", "bce_import_keys_file", "bce_export_keys_file", "bce_bsk_words", "bce_ksk_words", "bce_export_sk", "bce_export_bsk",
     "bce_export_ksk", "bce_pool_reserve", "bce_pool_slots", "bce_lwe_write", "bce_lwe_read",
     "bce_encrypt_bits", "bce_set_encrypt_seed", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize",
-    "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_forward_transforms_per_step", "bce_launch_capacity", "bce_rccl_available", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
+    "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_forward_transforms_per_step", "bce_launch_capacity", "bce_rccl_available", "bce_rccl_version", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
     "bce_rccl_shutdown", "bce_debug_eval_stages", "bce_debug_ntt",
     "bce_dag_supported", "bce_dag_create", "bce_dag_run", "bce_dag_destroy", "bce_dag_set_limits", "bce_dag_last_run", "bce_dag_debug_block_task",
 ]
@@ -91,6 +91,8 @@ def lib():
     L.bce_get_params.argtypes = [vp, C.POINTER(u64)]
     L.bce_keygen.argtypes = [vp, C.c_char_p]
     L.bce_import_keys.argtypes = [vp, vp, vp, vp, u64, vp, u64]
+    L.bce_import_keys_eval.argtypes = [vp, vp, vp, vp, u64, vp, u64]
+    L.bce_export_bsk_eval.argtypes = [vp, vp]
     L.bce_import_keys_file.argtypes = [vp, C.c_char_p]
     L.bce_export_keys_file.argtypes = [vp, C.c_char_p]
     L.bce_bsk_words.argtypes = [vp]
@@ -203,6 +205,19 @@ class BinFHEContext:
         bsk = np.ascontiguousarray(bsk, dtype=np.uint64)
         ksk = np.ascontiguousarray(ksk, dtype=np.uint32)
         self._ck(self._L.bce_import_keys(self.h, _p(s), _p(z), _p(bsk), bsk.size, _p(ksk), ksk.size))
+
+    def import_keys_eval(self, s, z, bsk_eval, ksk):
+        """bootstrapping key already in EVALUATION form, OpenFHE's order (bit-reversed CT order, minimal primitive root)"""
+        s = np.ascontiguousarray(s, dtype=np.int32)
+        z = np.ascontiguousarray(z, dtype=np.int32)
+        bsk = np.ascontiguousarray(bsk_eval, dtype=np.uint64)
+        ksk = np.ascontiguousarray(ksk, dtype=np.uint32)
+        self._ck(self._L.bce_import_keys_eval(self.h, _p(s), _p(z), _p(bsk), bsk.size, _p(ksk), ksk.size))
+
+    def export_bsk_eval(self):
+        out = np.zeros(self._L.bce_bsk_words(self.h), dtype=np.uint64)
+        self._ck(self._L.bce_export_bsk_eval(self.h, _p(out)))
+        return out
 
     def import_keys_file(self, path):
         """keys written by tools/openfhe_export/export_keys.cpp (format: tools/openfhe_export/bce_keyfile.h)"""
@@ -347,6 +362,9 @@ class BinFHEContext:
     def rccl_init(self, uid, rank, world):
         self._ck(self._L.bce_rccl_init(self.h, bytes(uid), int(rank), int(world)))
 
+    def rccl_shutdown(self):
+        self._ck(self._L.bce_rccl_shutdown(self.h))
+
     def rccl_allgather(self, dev_send_ptr, dev_recv_ptr, nbytes):
         self._ck(self._L.bce_rccl_allgather(self.h, C.c_void_p(dev_send_ptr), C.c_void_p(dev_recv_ptr), int(nbytes)))
 
@@ -354,6 +372,17 @@ class BinFHEContext:
         buf = (C.c_uint64 * 3)()
         self._ck(self._L.bce_bytes_per_bootstrap_parts(self.h, buf))
         return {"bsk": int(buf[0]), "ksk": int(buf[1]), "ct": int(buf[2])}
+
+    def is64(self):
+        """ring modulus >= 2^28: the 64-bit kernels (kernels64.hip)"""
+        return self.params["Q"] >= (1 << 28)
+
+    def fp64(self):
+        """64-bit path computing with exact integers in IEEE doubles (Q < 2^39, unless BCE_FP64=0)"""
+        return self.is64() and self.params["Q"] < (1 << 39) and os.environ.get("BCE_FP64", "1")[:1] != "0"
+
+    def bsk_word_bytes(self):
+        return 8 if self.is64() else 4
 
     def forward_transforms_per_step(self):
         return int(self._L.bce_forward_transforms_per_step(self.h))
@@ -403,7 +432,7 @@ CIRCUIT_SYMBOLS = [
     "bce_circuit_create", "bce_circuit_destroy", "bce_circuit_last_error", "bce_circuit_read_file",
     "bce_circuit_read_bristol", "bce_circuit_get_info", "bce_circuit_reset", "bce_circuit_rearm", "bce_circuit_set_plaintext",
     "bce_circuit_set_encrypted", "bce_circuit_set_verify", "bce_circuit_get_flags", "bce_circuit_set_batched",
-    "bce_circuit_set_encrypt_mode", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_dataflow", "bce_circuit_dataflow_active", "bce_circuit_set_balance", "bce_circuit_relevel_steps", "bce_circuit_relevel_publications", "bce_circuit_check_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
+    "bce_circuit_set_encrypt_mode", "bce_circuit_get_encrypt_mode", "bce_circuit_plan_hash", "bce_circuit_set_shard_locality", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_dataflow", "bce_circuit_dataflow_active", "bce_circuit_dataflow_plan", "bce_circuit_set_balance", "bce_circuit_relevel_steps", "bce_circuit_relevel_publications", "bce_circuit_check_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
     "bce_circuit_get_output", "bce_circuit_get_buses", "bce_circuit_get_counts", "bce_circuit_get_stats", "bce_circuit_dump",
     "bce_circuit_set_exchange", "bce_circuit_enable_rccl", "bce_circuit_exchange_capacity", "bce_assemble_bristol", "bce_pool_gather",
     "bce_pool_scatter",
@@ -434,7 +463,12 @@ def _bind_circuit():
     L.bce_circuit_set_instances.argtypes = [vp, u32]
     L.bce_circuit_set_balance.argtypes = [vp, i32, u32, u32]
     L.bce_circuit_set_dataflow.argtypes = [vp, i32]
+    L.bce_circuit_get_encrypt_mode.argtypes = [vp]
+    L.bce_circuit_set_shard_locality.argtypes = [vp, i32]
+    L.bce_circuit_plan_hash.argtypes = [vp]
+    L.bce_circuit_plan_hash.restype = u64
     L.bce_circuit_dataflow_active.argtypes = [vp]
+    L.bce_circuit_dataflow_plan.argtypes = [vp, vp, vp, u32, C.POINTER(u32)]
     L.bce_circuit_relevel_steps.argtypes = [vp, C.POINTER(u32), u32, C.POINTER(u32)]
     L.bce_circuit_relevel_publications.argtypes = [vp, C.POINTER(u32), u32, C.POINTER(u32)]
     L.bce_circuit_check_relevel.argtypes = [vp]
@@ -567,7 +601,19 @@ class Circuit:
         self._ck(self._L.bce_circuit_set_batched(self.h, int(b)))
 
     def setEncryptMode(self, mode):
+        """BOOTSTRAPPED (default, OpenFHE v1.0.x's cc.Encrypt) or FRESH"""
         self._ck(self._L.bce_circuit_set_encrypt_mode(self.h, int(mode)))
+
+    def setShardLocality(self, on):
+        """gate sharding: units follow their inputs' ranks (default) / contiguous split in netlist order"""
+        self._ck(self._L.bce_circuit_set_shard_locality(self.h, int(on)))
+
+    def plan_hash(self):
+        """digest of the sharding plan: must be equal on every rank of a run"""
+        return int(self._L.bce_circuit_plan_hash(self.h))
+
+    def getEncryptMode(self):
+        return int(self._L.bce_circuit_get_encrypt_mode(self.h))
 
     def setXorFast(self, b):
         """opt-in, not reference semantics: XOR as one XOR_FAST bootstrap"""
@@ -580,6 +626,15 @@ class Circuit:
     def setDataflow(self, b):
         """opt-in: the whole bootstrap DAG in one persistent launch (device-side ready-gate rule); before SetInput"""
         self._ck(self._L.bce_circuit_set_dataflow(self.h, int(b)))
+
+    def dataflow_plan(self):
+        """(tasks, priority classes) of the dataflow schedule: tasks = (op, in0, in1, out, neg0, neg1), one instance"""
+        n = C.c_uint32(0)
+        self._ck(self._L.bce_circuit_dataflow_plan(self.h, None, None, 0, C.byref(n)))
+        arr = (GateDesc * max(1, n.value))()
+        pr = (C.c_uint8 * max(1, n.value))()
+        self._ck(self._L.bce_circuit_dataflow_plan(self.h, arr, pr, n.value, C.byref(n)))
+        return ([(a.op, a.in0, a.in1, a.out, a.neg0, a.neg1) for a in arr[:n.value]], [int(x) for x in pr[:n.value]])
 
     def dataflowActive(self):
         return bool(self._L.bce_circuit_dataflow_active(self.h))

@@ -65,7 +65,7 @@ static void verify_fix(const GateEvalParams& gep, const char* opn, CipherText sl
         if (fix) {
             uint8_t bit = (uint8_t)expect;
             uint64_t idx = gep.enc_counter ? (*gep.enc_counter)++ : 0;
-            gate_ck(gep, bce_encrypt_bits(gep.cc, &bit, &slot, 1, idx, BCE_FRESH), name);
+            gate_ck(gep, bce_encrypt_bits(gep.cc, &bit, &slot, 1, idx, gep.encrypt_mode), name);
         }
     }
 }
@@ -548,6 +548,16 @@ void Circuit::setExchange(uint32_t rank, uint32_t world, int shard_mode, bce_all
     rebuildRelevel();   // the number of instances this rank evaluates may have changed
 }
 
+uint64_t Circuit::planHash() const {
+    uint64_t h = 0xcbf29ce484222325ull;   // FNV-1a over 64-bit words
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 0x100000001b3ull; };
+    mix(world_); mix((uint64_t)shard_mode_); mix(stride_); mix(instances_); mix(relevel_ ? 1 : 0); mix(xor_fast_ ? 1 : 0);
+    for (const auto& lv : owner_) { mix(lv.size()); for (uint8_t o : lv) mix(o); }
+    for (const auto& lv : xwires_) for (const auto& r : lv) { mix(r.size()); for (int w : r) mix((uint64_t)w); }
+    for (const auto& st : relevel_xw_) for (const auto& r : st) { mix(r.size()); for (int w : r) mix((uint64_t)w); }
+    return h;
+}
+
 // after a level: publish wires whose consumers sit on other ranks (shard_mode 1)
 void Circuit::exchangeLevel(size_t level) {
     if (world_ <= 1 || shard_mode_ != 1) return;
@@ -778,24 +788,85 @@ void Circuit::buildRelevelPlan() {
     if (sharded) {
         std::vector<std::vector<uint32_t>> by_step(D + 2);
         for (size_t i = 0; i < U; ++i) by_step[units[i].start].push_back((uint32_t)i);
+        auto assign_owners = [&](bool locality) {
         std::vector<uint64_t> carried(world_, 0), next_carried(world_, 0);
         for (uint32_t st = 1; st <= D; ++st) {
             uint64_t total = 0;
             for (uint32_t r = 0; r < world_; ++r) total += carried[r];
             for (uint32_t i : by_step[st]) total += units[i].lat == 2 ? 2 : 1;
             std::fill(next_carried.begin(), next_carried.end(), 0);
-            // contiguous split in netlist order: rank r ends where the running load (carried ORs of ranks <= r + the units
-            // given out so far) reaches (r + 1) / world of the step's total (midpoint rule: within one unit of the fair share)
-            uint32_t r = 0;
-            uint64_t cum = carried[0];
-            for (uint32_t i : by_step[st]) {
-                const uint64_t w = units[i].lat == 2 ? 2 : 1;
-                while (r + 1 < world_ && (2 * cum + w) * world_ > 2 * (uint64_t)(r + 1) * total) { ++r; cum += carried[r]; }
-                units[i].owner = (uint8_t)r;
-                cum += w;
-                if (units[i].lat == 2) ++next_carried[r];
+            if (!locality) {
+                // contiguous split in netlist order: rank r ends where the running load (carried ORs of ranks <= r + the units
+                // given out so far) reaches (r + 1) / world of the step's total (midpoint rule: within one unit of the fair share)
+                uint32_t r = 0;
+                uint64_t cum = carried[0];
+                for (uint32_t i : by_step[st]) {
+                    const uint64_t w = units[i].lat == 2 ? 2 : 1;
+                    while (r + 1 < world_ && (2 * cum + w) * world_ > 2 * (uint64_t)(r + 1) * total) { ++r; cum += carried[r]; }
+                    units[i].owner = (uint8_t)r;
+                    cum += w;
+                    if (units[i].lat == 2) ++next_carried[r];
+                }
+            } else {
+                // locality first ("schedule a gate on the GPU that produced most of its inputs"), balance as the
+                // constraint: every rank may take up to its fair share of the step's bootstraps (rounded up, + one unit so that
+                // an XOR's pair never has to split).  Units whose two producers sit on one rank choose first, then those with
+                // one producing rank, then the free ones fill the least loaded ranks.  Deterministic: every rank computes it.
+                const uint64_t share = (total + world_ - 1) / world_ + 1;
+                std::vector<uint64_t> load(carried);
+                std::vector<uint32_t> rest;
+                auto place = [&](uint32_t i, uint32_t r) {
+                    units[i].owner = (uint8_t)r;
+                    load[r] += units[i].lat == 2 ? 2 : 1;
+                    if (units[i].lat == 2) ++next_carried[r];
+                };
+                auto owner_of = [&](int32_t p) -> int { return p >= 0 ? (int)units[p].owner : -1; };
+                for (int pass = 0; pass < 2; ++pass)
+                    for (uint32_t i : by_step[st]) {
+                        const uint64_t w = units[i].lat == 2 ? 2 : 1;
+                        const int a = owner_of(units[i].p0), b = owner_of(units[i].p1);
+                        const bool both = a >= 0 && a == b;
+                        if (pass == 0) {
+                            if (both && load[a] + w <= share) place(i, (uint32_t)a);
+                            else if (!both) continue;
+                            else rest.push_back(i);
+                        } else if (!both) {
+                            // one producing rank, or two different ones: the lighter of them if it has room
+                            int c = -1;
+                            if (a >= 0 && load[a] + w <= share) c = a;
+                            if (b >= 0 && load[b] + w <= share && (c < 0 || load[b] < load[c])) c = b;
+                            if (c >= 0) place(i, (uint32_t)c); else rest.push_back(i);
+                        }
+                    }
+                std::sort(rest.begin(), rest.end());   // netlist order
+                for (uint32_t i : rest) {
+                    uint32_t r = 0;
+                    for (uint32_t k = 1; k < world_; ++k) if (load[k] < load[r]) r = k;
+                    place(i, r);
+                }
             }
             carried.swap(next_carried);
+        }
+        };
+        // outputs that cross ranks under an assignment (consumers elsewhere; OUTPUT gates are read by every rank either way)
+        auto crossings = [&]() {
+            std::vector<uint8_t> x(U, 0);
+            for (size_t i = 0; i < U; ++i) {
+                const Unit& u = units[i];
+                if (u.p0 >= 0 && units[u.p0].owner != u.owner) x[u.p0] = 1;
+                if (u.p1 >= 0 && units[u.p1].owner != u.owner) x[u.p1] = 1;
+            }
+            uint64_t n = 0;
+            for (uint8_t v : x) n += v;
+            return n;
+        };
+        assign_owners(false);
+        if (shard_locality_) {
+            // keep whichever split publishes less: netlist order already is a locality order for some circuits (sha256 on two
+            // ranks), input-following placement wins on others (AES-expanded on eight: 21.0 k -> 11.9 k crossing outputs)
+            const uint64_t contiguous = crossings();
+            assign_owners(true);
+            if (crossings() > contiguous) assign_owners(false);
         }
         // publications: an output crosses when a consumer unit sits on another rank, or when an OUTPUT gate reads it (every
         // rank decrypts every output, as in the gate-level plan); it is published after the step that produces it
@@ -1162,7 +1233,7 @@ void Circuit::executeRound(size_t level) {
                 std::cerr << "Bad " << names[k] << " fixing" << std::endl;
                 ++stats_.verify_fixes;
                 if (std::strcmp(names[k], "OUTPUT") != 0)
-                    ck(bce_encrypt_bits(cc, &expect[k], &slots[k], 1, (1ull << 40) + enc_counter_++, BCE_FRESH), "Clock(fix)");
+                    ck(bce_encrypt_bits(cc, &expect[k], &slots[k], 1, (1ull << 40) + enc_counter_++, encrypt_mode_), "Clock(fix)");
             }
         }
     }

@@ -59,6 +59,7 @@ public:
     bool verify_flag = false;
     bce_ctx* cc = nullptr;
     bool xor_fast = false;            // opt-in: XOR as ONE bootstrap of 2*(ct1-ct2) (BCE_XOR_FAST), not the reference's 3
+    int encrypt_mode = BCE_BOOTSTRAPPED;  // output mode of the verify-mode re-encryptions (cc.Encrypt(sk, bit), src/gate.cpp:118,...)
     uint64_t* enc_counter = nullptr;  // PRNG stream index for verify-mode re-encryptions
     unsigned int* fixes = nullptr;    // counts "Bad <OP> fixing" events
 };
@@ -115,7 +116,11 @@ public:
     void setInstances(unsigned k);            // K lock-step input sets (before SetInput)
     unsigned getInstances() const { return instances_; }
     void setBatched(bool b) { batched_ = b; }
-    void setEncryptMode(int mode) { encrypt_mode_ = mode; }
+    // cc.Encrypt(sk, bit) of SetInput (src/circuit.cpp:506) and of the verify-mode repairs (src/gate.cpp:118,139,143,158,179,211):
+    // BCE_BOOTSTRAPPED by default, as OpenFHE v1.0.x's Encrypt defaults to BOOTSTRAPPED (one Bootstrap per fresh ciphertext);
+    // BCE_FRESH is the opt-in that skips it
+    void setEncryptMode(int mode) { encrypt_mode_ = gep.encrypt_mode = mode; }
+    int getEncryptMode() const { return encrypt_mode_; }
     // opt-in, NOT the reference's semantics: evaluate XOR natively with OpenFHE's XOR_FAST gate
     // (src/gate.cpp:194-196 disables it "for now" because of its higher failure rate)
     void setXorFast(bool b);
@@ -136,7 +141,8 @@ public:
     void setDataflow(bool b);
     bool getDataflow() const { return dataflow_; }
     bool dataflowActive() const;
-    uint32_t dataflowTasks() const { return (uint32_t)dag_tasks_.size(); }
+    const std::vector<bce_gate_desc>& dataflowTasks() const { return dag_tasks_; }
+    const std::vector<uint8_t>& dataflowPriorities() const { return dag_prio_; }
     bool getBalance() const { return balance_; }
     std::vector<uint32_t> relevelStepSizes() const;          // bootstraps per step, one instance
     std::vector<uint32_t> relevelPublications() const;       // registers this rank publishes per step (gate sharding)
@@ -156,6 +162,14 @@ public:
                      void* host_recv, void* dev_send, void* dev_recv, uint64_t capacity);
     uint64_t exchangeCapacity(uint32_t world, int shard_mode, bool encrypted) const;
     void enableRccl(bool on) { rccl_ = on; }
+    // gate sharding: place a unit on the rank that produced (most of) its inputs, within the fair share of each step
+    // (default); off = contiguous split in netlist order.  Every rank must choose the same.
+    void setShardLocality(bool on) { shard_locality_ = on; if (world_ > 1) rebuildRelevel(); }
+    bool getShardLocality() const { return shard_locality_; }
+    // digest of everything the ranks of a gate-sharded run must agree on (owners, publications per step, slot stride,
+    // instances): ranks whose devices or environment knobs differ would otherwise build different plans and exchange
+    // buffers of different sizes -- compare it across ranks before the first Clock()
+    uint64_t planHash() const;
     bce_ctx* engine() const { return cc; }
 
 private:
@@ -178,7 +192,7 @@ private:
     bool owns_engine_ = false;
     bool plaintext_flag = false, encrypted_flag = false, verify_flag = false;
     bool done = false, inputs_set_ = false, quiet_ = false, batched_ = true, xor_fast_ = false;
-    int encrypt_mode_ = BCE_FRESH;
+    int encrypt_mode_ = BCE_BOOTSTRAPPED;
     GateEvalParams gep;
 
     std::vector<LoadRec> inputGates;  // LOADs
@@ -212,6 +226,7 @@ private:
     void *host_send_ = nullptr, *host_recv_ = nullptr, *dev_send_ = nullptr, *dev_recv_ = nullptr;
     uint64_t xcap_ = 0;
     bool rccl_ = false;  // device payloads through bce_rccl_allgather on the engine stream (no host sync, no callback)
+    bool shard_locality_ = true;  // gate sharding on the bootstrap-depth schedule: a unit goes to the rank that produced its inputs
     std::vector<std::vector<uint8_t>> owner_;                 // [level][k] owner rank of levels_[level].gates[k]
     std::vector<std::vector<std::vector<int>>> xwires_;       // [level][rank] -> wires that rank must publish
 

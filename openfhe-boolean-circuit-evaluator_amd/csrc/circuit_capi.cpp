@@ -1,5 +1,6 @@
 // circuit_capi.cpp -- extern "C" wrappers of include/bce_circuit.h over bce::Circuit.
 // C++ exceptions stop here and become bce_status codes + bce_circuit_last_error().
+#include <algorithm>
 #include <cstring>
 #include <exception>
 #include <new>
@@ -82,8 +83,21 @@ int bce_circuit_set_encrypt_mode(bce_circuit* h, int mode) {
 int bce_circuit_set_xor_fast(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setXorFast(on != 0); }); }
 int bce_circuit_set_relevel(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setRelevel(on != 0); }); }
 int bce_circuit_set_instances(bce_circuit* h, uint32_t k) { return guarded(h, [&] { h->c.setInstances(k); }); }
+int bce_circuit_set_shard_locality(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setShardLocality(on != 0); }); }
+uint64_t bce_circuit_plan_hash(const bce_circuit* h) { return h ? h->c.planHash() : 0; }
+int bce_circuit_get_encrypt_mode(const bce_circuit* h) { return h ? h->c.getEncryptMode() : -1; }
 int bce_circuit_set_dataflow(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setDataflow(on != 0); }); }
 int bce_circuit_dataflow_active(const bce_circuit* h) { return h && h->c.dataflowActive() ? 1 : 0; }
+int bce_circuit_dataflow_plan(const bce_circuit* h, bce_gate_desc* tasks, uint8_t* prio, uint32_t cap, uint32_t* n_tasks) {
+    if (!h || !n_tasks) return BCE_ERR_ARG;
+    const auto& t = h->c.dataflowTasks();
+    const auto& p = h->c.dataflowPriorities();
+    const uint32_t n = (uint32_t)std::min<size_t>(t.size(), cap);
+    if (tasks) std::copy(t.begin(), t.begin() + n, tasks);
+    if (prio) std::copy(p.begin(), p.begin() + n, prio);
+    *n_tasks = (uint32_t)t.size();
+    return BCE_OK;
+}
 int bce_circuit_set_balance(bce_circuit* h, int on, uint32_t lone, uint32_t full) { return guarded(h, [&] { h->c.setBalance(on != 0, lone, full); }); }
 int bce_circuit_relevel_steps(const bce_circuit* h, uint32_t* sizes, uint32_t cap, uint32_t* n_steps) {
     if (!h || !n_steps || (cap && !sizes)) return BCE_ERR_ARG;

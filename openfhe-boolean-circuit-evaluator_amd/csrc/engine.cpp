@@ -725,8 +725,21 @@ int bce_keygen(bce_ctx* c, const uint8_t seed_in[32]) {
     return BCE_OK;
 }
 
+static int import_keys_impl(bce_ctx* c, const int32_t* s, const int32_t* z, const uint64_t* bsk, uint64_t bsk_words,
+                            const uint32_t* ksk, uint64_t ksk_words, bool evaluation_form);
+
 int bce_import_keys(bce_ctx* c, const int32_t* s, const int32_t* z, const uint64_t* bsk, uint64_t bsk_words,
                     const uint32_t* ksk, uint64_t ksk_words) {
+    return import_keys_impl(c, s, z, bsk, bsk_words, ksk, ksk_words, false);
+}
+
+int bce_import_keys_eval(bce_ctx* c, const int32_t* s, const int32_t* z, const uint64_t* bsk_eval, uint64_t bsk_words,
+                         const uint32_t* ksk, uint64_t ksk_words) {
+    return import_keys_impl(c, s, z, bsk_eval, bsk_words, ksk, ksk_words, true);
+}
+
+static int import_keys_impl(bce_ctx* c, const int32_t* s, const int32_t* z, const uint64_t* bsk, uint64_t bsk_words,
+                            const uint32_t* ksk, uint64_t ksk_words, bool evaluation_form) {
     if (!c || !s || !bsk || !ksk) return c ? c->fail(BCE_ERR_ARG, "null key pointer") : BCE_ERR_ARG;
     if (bsk_words != bce_bsk_words(c) || ksk_words != bce_ksk_words(c)) return c->fail(BCE_ERR_ARG, "key sizes do not match the parameter set");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -734,7 +747,10 @@ int bce_import_keys(bce_ctx* c, const int32_t* s, const int32_t* z, const uint64
     if (rc) return rc;
     c->s.assign(s, s + c->n);
     if (z) c->z.assign(z, z + c->N); else c->z.clear();
-    {   // coefficient-domain words -> device words, chunked; then NTT in place on the device
+    std::memset(c->seed, 0, sizeof c->seed);   // imported keys have no generation seed
+    {   // words -> device words, chunked; coefficient-domain words are then transformed in place on the device
+        // (evaluation-form words arrive in the engine's own order: OpenFHE's bit-reversed CT order for the minimal
+        // primitive 2N-th root, bce_get_params()[BCE_P_psi])
         const u64 chunk = (u64)64 << 20;
         std::vector<u32> tmp32;
         for (u64 o = 0; o < bsk_words; o += chunk) {
@@ -749,8 +765,7 @@ int bce_import_keys(bce_ctx* c, const int32_t* s, const int32_t* z, const uint64
                 HIP_TRY(c, hipMemcpy(static_cast<u32*>(c->d_bsk) + o, tmp32.data(), cnt * 4, hipMemcpyHostToDevice));
             }
         }
-        rc = dev_ntt(c, c->d_bsk, bsk_words / c->N, 0);
-        if (rc) return rc;
+        if (!evaluation_form && (rc = dev_ntt(c, c->d_bsk, bsk_words / c->N, 0))) return rc;
         if ((rc = bsk_words_to_kernel_layout(c))) return rc;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
@@ -767,7 +782,10 @@ int bce_export_sk(const bce_ctx* c, int32_t* s, int32_t* z) {
     return BCE_OK;
 }
 
-int bce_export_bsk(bce_ctx* c, uint64_t* bsk) {
+static int export_bsk_impl(bce_ctx* c, uint64_t* bsk, bool evaluation_form);
+int bce_export_bsk(bce_ctx* c, uint64_t* bsk) { return export_bsk_impl(c, bsk, false); }
+
+static int export_bsk_impl(bce_ctx* c, uint64_t* bsk, bool evaluation_form) {
     if (!c || !bsk) return BCE_ERR_ARG;
     if (!c->have_keys) return c->fail(BCE_ERR_NO_KEYS, "no keys");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -784,8 +802,7 @@ int bce_export_bsk(bce_ctx* c, uint64_t* bsk) {
         HIP_TRY(c, hipMemcpyAsync(d_tmp, src, w * c->wbytes, hipMemcpyDeviceToDevice, c->stream));
         if (c->P.fp64) HIP_TRY(c, launch_words_u64_f64(static_cast<u64*>(d_tmp), w, 0, c->stream));  // doubles -> u64 words
         if (c->P.fold) HIP_TRY(c, launch_fold_gadget(c->P, d_tmp, cnt / (4ull * c->dG), -1, c->stream));   // rows l >= 1 += B^l row 0
-        int rc = dev_ntt(c, d_tmp, cnt, 1);
-        if (rc) return rc;
+        if (!evaluation_form) { int rc = dev_ntt(c, d_tmp, cnt, 1); if (rc) return rc; }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->is64) {
             HIP_TRY(c, hipMemcpy(bsk + p0 * c->N, d_tmp, w * 8, hipMemcpyDeviceToHost));
@@ -797,6 +814,8 @@ int bce_export_bsk(bce_ctx* c, uint64_t* bsk) {
     }
     return BCE_OK;
 }
+
+int bce_export_bsk_eval(bce_ctx* c, uint64_t* bsk) { return export_bsk_impl(c, bsk, true); }
 
 int bce_export_ksk(bce_ctx* c, uint32_t* ksk) {
     if (!c || !ksk) return BCE_ERR_ARG;

@@ -78,7 +78,11 @@ int bce_import_keys_file(bce_ctx* c, const char* path) {
     const uint32_t* ksk = reinterpret_cast<const uint32_t*>(base + bsk_off + h.bsk_words * 8);
     for (uint64_t i = 0; i < h.ksk_words; ++i)
         if (ksk[i] >= h.qKS) return bce_set_error(c, BCE_ERR_ARG, "key file: key-switching word not reduced mod qKS");
-    return bce_import_keys(c, s, z, bsk, h.bsk_words, ksk, h.ksk_words);
+    if (h.bsk_format > BCE_KEYFILE_BSK_EVALUATION) return bce_set_error(c, BCE_ERR_UNSUPPORTED, "key file: unknown bootstrapping-key representation");
+    for (uint64_t k = 0; h.has_z && k < h.N; ++k)
+        if (z[k] < -1 || z[k] > 1) return bce_set_error(c, BCE_ERR_ARG, "key file: ring secret entries must be -1, 0 or 1");
+    return h.bsk_format == BCE_KEYFILE_BSK_EVALUATION ? bce_import_keys_eval(c, s, z, bsk, h.bsk_words, ksk, h.ksk_words)
+                                                      : bce_import_keys(c, s, z, bsk, h.bsk_words, ksk, h.ksk_words);
 }
 
 int bce_export_keys_file(bce_ctx* c, const char* path) {
@@ -93,19 +97,24 @@ int bce_export_keys_file(bce_ctx* c, const char* path) {
     h.baseKS = p[BCE_P_baseKS]; h.baseG = p[BCE_P_baseG]; h.baseR = p[BCE_P_baseR];
     h.bsk_words = bce_bsk_words(c);
     h.ksk_words = bce_ksk_words(c);
-    std::vector<int32_t> s(h.n), z(h.N, 0);
+    // z = N entries of 2 marks "not exported": contexts whose keys were imported without the ring secret have none
+    std::vector<int32_t> s(h.n), z(h.N, 2);
     int rc = bce_export_sk(c, s.data(), z.data());
     if (rc) return bce_set_error(c, rc, "no keys to export");
-    h.has_z = 1;
+    h.has_z = (h.N > 0 && z[0] != 2) ? 1 : 0;
     std::vector<uint64_t> bsk(h.bsk_words);
     if ((rc = bce_export_bsk(c, bsk.data()))) return rc;
     std::vector<uint32_t> ksk(h.ksk_words);
     if ((rc = bce_export_ksk(c, ksk.data()))) return rc;
-    FILE* f = std::fopen(path, "wb");
-    if (!f) return bce_set_error(c, BCE_ERR_ARG, (std::string("cannot open ") + path + " for writing").c_str());
+    // the file holds the secret keys: owner-only permissions whatever the umask says
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0600);
+    FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+    if (!f) { if (fd >= 0) close(fd); return bce_set_error(c, BCE_ERR_ARG, (std::string("cannot open ") + path + " for writing").c_str()); }
+    if (fchmod(fd, 0600) != 0) { std::fclose(f); return bce_set_error(c, BCE_ERR_STATE, "cannot restrict the key file's permissions"); }
+    const uint64_t zn = h.has_z ? h.N : 0;
     bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
-    ok = ok && std::fwrite(s.data(), 4, h.n, f) == h.n && std::fwrite(z.data(), 4, h.N, f) == h.N;
-    if (ok && ((h.n + h.N) & 1)) { const uint32_t zero = 0; ok = std::fwrite(&zero, 4, 1, f) == 1; }
+    ok = ok && std::fwrite(s.data(), 4, h.n, f) == h.n && std::fwrite(z.data(), 4, zn, f) == zn;
+    if (ok && ((h.n + zn) & 1)) { const uint32_t zero = 0; ok = std::fwrite(&zero, 4, 1, f) == 1; }
     ok = ok && std::fwrite(bsk.data(), 8, h.bsk_words, f) == h.bsk_words && std::fwrite(ksk.data(), 4, h.ksk_words, f) == h.ksk_words;
     ok = (std::fclose(f) == 0) && ok;
     return ok ? BCE_OK : bce_set_error(c, BCE_ERR_STATE, "short write to the key file");

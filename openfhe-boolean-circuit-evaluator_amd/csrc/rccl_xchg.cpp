@@ -32,6 +32,7 @@ using CommInitRankFn = int (*)(void**, int, UniqueId, int);
 using CommDestroyFn = int (*)(void*);
 using AllGatherFn = int (*)(const void*, void*, size_t, int, void*, hipStream_t);
 using ErrStrFn = const char* (*)(int);
+using GetVersionFn = int (*)(int*);
 
 struct Rccl {
     void* handle = nullptr;
@@ -40,6 +41,7 @@ struct Rccl {
     CommDestroyFn comm_destroy = nullptr;
     AllGatherFn all_gather = nullptr;
     ErrStrFn err_str = nullptr;
+    int version = 0;   // ncclGetVersion: the prototypes above are those of the 2.x ABI (rccl.h of ROCm 6 / 7)
     std::string why;
 };
 
@@ -60,8 +62,17 @@ Rccl& rccl() {
         x.comm_destroy = (CommDestroyFn)dlsym(x.handle, "ncclCommDestroy");
         x.all_gather = (AllGatherFn)dlsym(x.handle, "ncclAllGather");
         x.err_str = (ErrStrFn)dlsym(x.handle, "ncclGetErrorString");
-        if (!x.get_unique_id || !x.comm_init_rank || !x.comm_destroy || !x.all_gather || !x.err_str) {
+        GetVersionFn get_version = (GetVersionFn)dlsym(x.handle, "ncclGetVersion");
+        if (!x.get_unique_id || !x.comm_init_rank || !x.comm_destroy || !x.all_gather || !x.err_str || !get_version) {
             x.why = "RCCL library lacks an expected entry point";
+            dlclose(x.handle);
+            x.handle = nullptr;
+            return x;
+        }
+        // the hand-declared prototypes are the NCCL 2.x ones (ncclUniqueId by value, ncclDataType_t ncclUint8 = 1): refuse
+        // a library that reports another major version instead of calling into it with the wrong ABI
+        if (get_version(&x.version) != 0 || x.version < 20000 || x.version >= 30000) {
+            x.why = "RCCL library reports version " + std::to_string(x.version) + ": the in-library exchange is written against the 2.x ABI";
             dlclose(x.handle);
             x.handle = nullptr;
         }
@@ -80,6 +91,7 @@ int fail_nccl(bce_ctx* c, const char* what, int rc) {
 extern "C" {
 
 int bce_rccl_available(void) { return rccl().handle ? 1 : 0; }
+int bce_rccl_version(void) { return rccl().handle ? rccl().version : 0; }
 
 int bce_rccl_unique_id(uint8_t out[128]) {
     if (!out) return BCE_ERR_ARG;

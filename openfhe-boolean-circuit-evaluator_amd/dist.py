@@ -50,14 +50,30 @@ class Exchange:
                                  self.host_send.data_ptr(), self.host_recv.data_ptr(),
                                  self.dev_send.data_ptr() if device is not None else None,
                                  self.dev_recv.data_ptr() if device is not None else None, cap)
+        self._check_plans_agree(circuit)
         if in_library and device is not None and encrypted:
             self._setup_in_library(circuit)
+
+    def _check_plans_agree(self, circuit):
+        """every rank builds the sharding plan itself (from its device's launch capacity and environment): different plans
+        would mean all-gathers of different sizes -- a hang or silently wrong registers.  One MIN / MAX all-reduce of the
+        plan digest settles it before the first evaluation."""
+        h = circuit.plan_hash()
+        dev = self.device if dist.get_backend(self.group) == "nccl" else "cpu"
+        parts = torch.tensor([h & 0x7FFFFFFF, (h >> 31) & 0x7FFFFFFF, h >> 62], dtype=torch.int64, device=dev)
+        lo, hi = parts.clone(), parts.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("the ranks built different sharding plans (different devices or BCE_* environment knobs?): "
+                               "rank %d has digest %016x" % (self.rank, h))
 
     def _setup_in_library(self, circuit):
         """Every step that could leave the ranks disagreeing is agreed on first (all-reduce of a flag), so that either
         ALL ranks enter ncclCommInitRank or none does."""
         on_gpu = dist.get_backend(self.group) == "nccl"
         dev = self.device if on_gpu else "cpu"
+        self.why = ""      # from here on `why` holds a REASON (it starts as the truthy "not requested")
 
         def all_ok(ok):
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
@@ -86,6 +102,11 @@ class Exchange:
             circuit.enable_rccl(True)
             self.in_library, self.why = True, ""
         else:
+            if ok:   # this rank's communicator exists but another rank's does not: give it back, all ranks use the callback
+                try:
+                    circuit.cc.rccl_shutdown()
+                except Exception:
+                    pass
             self.why = self.why or "another rank could not initialise RCCL"
 
     def _allgather(self, nbytes, on_device):
@@ -113,3 +134,60 @@ class Exchange:
         except Exception as e:  # never raise through the C callback
             print("exchange failed:", repr(e), flush=True)
             return 1
+
+
+def gate_registers(circuit_path, new_flag=False):
+    """registers (slot numbers of instance 0) that hold the output of a bootstrapped gate, and the circuit's input registers"""
+    import importlib
+    bce = importlib.import_module(__package__)
+    c = bce.Circuit()
+    c.ReadBristol(circuit_path, new_flag=new_flag)
+    c.setDataflow(True)
+    n_wires = c.info()["n_wires"]
+    tasks, _ = c.dataflow_plan()
+    n_in = c.info()["n_input_gates"]
+    c.close()
+    return sorted(t[3] for t in tasks if t[3] < n_wires), list(range(n_in))
+
+
+def check_against_single_rank(cc, circ, circuit_path, new_flag, relevel, instances):
+    """After a gate-sharded Clock() of `circ` (shard mode 1): every register of a bootstrapped gate this rank computed or
+    received must hold, bit for bit, what an un-sharded evaluation of the same input ciphertexts leaves there (replicated
+    keys, deterministic bootstraps).  Runs that reference evaluation on THIS rank for the first `instances` instances
+    (their input ciphertexts are copied from the sharded run's pool).  Returns (registers held, registers compared equal,
+    bootstrapped registers per instance); raises AssertionError on the first difference."""
+    import importlib
+    import numpy as np
+    bce = importlib.import_module(__package__)
+    regs, ins = gate_registers(circuit_path, new_flag)
+    regs = np.array(regs, dtype=np.uint32)
+    ins = np.array(ins, dtype=np.uint32)
+    stride = circ.info()["slot_stride"]
+    sharded = [cc.lwe_read(regs + k * stride) for k in range(instances)]
+    inputs = [cc.lwe_read(ins + k * stride) for k in range(instances)]
+    ref = bce.Circuit(cc)
+    ref.ReadBristol(circuit_path, new_flag=new_flag)
+    ref.setInstances(instances)
+    ref.Reset()
+    ref.setEncrypted(True)
+    ref.setEncryptMode(bce.FRESH)          # placeholders: the real input ciphertexts are copied in below
+    if relevel:
+        ref.setRelevel(True)
+    widths = [w for w in ref.info()["n_input_bits"] if w]
+    for k in range(instances):
+        ref.SetInput([[0] * w for w in widths], instance=k)
+    rstride = ref.info()["slot_stride"]
+    for k in range(instances):
+        cc.lwe_write(ins + k * rstride, inputs[k])
+    ref.Clock()
+    held = same = 0
+    for k in range(instances):
+        single = cc.lwe_read(regs + k * rstride)
+        have = sharded[k].any(axis=1)          # a register this rank neither computed nor received is still all zero
+        held += int(have.sum())
+        eq = (sharded[k] == single).all(axis=1)
+        bad = np.nonzero(have & ~eq)[0]
+        assert bad.size == 0, "gate-sharded register %d of instance %d differs from the single-rank evaluation" % (int(regs[bad[0]]), k)
+        same += int((have & eq).sum())
+    ref.close()
+    return held, same, int(regs.size)

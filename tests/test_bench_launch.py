@@ -57,11 +57,13 @@ def test_bench_gpus2_rehearsal_on_one_gpu():
 
 @pytest.mark.gpu
 def test_bench_headline_survives_a_hung_secondary_run():
-    """A rank that never reaches the gate-sharded run's collectives (simulated) must cost the `shard_gates` object
-    only: the watchdog prints the one JSON line with the headline and ends every rank."""
+    """A rank that never reaches the gate-sharded run's collectives (simulated) must not cost the headline: the watchdog
+    prints the one JSON line with it and ends every rank -- with a NON-ZERO exit code, because a process that touched the
+    GPU and hung in a collective is a failed run (the parent reports `ranks failed`)."""
     p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--circuit", "adder_32bit.txt", "--instances", "4",
               "--gates-steps", "1", "--gates-timeout", "25"], timeout=600, BCE_BENCH_TEST_HANG="1")
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode != 0, p.stderr[-3000:]
+    assert "ranks failed" in p.stderr
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, p.stdout
     d = json.loads(line[0])

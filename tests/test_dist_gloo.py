@@ -39,6 +39,18 @@ def _worker(rank, world, port, shard_mode, circuit, K, q):
         else:
             c.ReadBristol(os.path.join(kat.CIRCUITS, circuit))
         c.setInstances(K)
+        if os.environ.get("BCE_TEST_PLAN_MISMATCH") == "1":
+            # ranks that disagree on the launch capacities (different devices / environment knobs) build different plans
+            c.setRelevel(True)
+            c.setBalance(True, 8 + 8 * rank, 16 + 16 * rank)
+            try:
+                xmod.Exchange(c, shard_mode, encrypted=False, device=None)
+                q.put((rank, False, "plan mismatch went unnoticed", 0))
+            except RuntimeError as e:
+                q.put((rank, "different sharding plans" in str(e), 0, 0))
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         x = xmod.Exchange(c, shard_mode, encrypted=False, device=None)
         nbits = c.info()["n_input_bits"][0]
         if rand_eval is not None:
@@ -71,11 +83,11 @@ def _worker(rank, world, port, shard_mode, circuit, K, q):
 def _run(shard_mode, circuit, K, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + shard_mode * 7
+    port = 29500 + (os.getpid() % 2000) + shard_mode * 7 + world * 13 + K
     procs = [ctx.Process(target=_worker, args=(r, world, port, shard_mode, circuit, K, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     return sorted(res)
@@ -108,4 +120,31 @@ def test_gate_sharding_random_netlist(seed):
     """constants, MAND, wire copies and several input / output values under gate sharding"""
     res = _run(1, "random:%d" % seed, K=2)
     for rank, ok, calls, exchanges in res:
+        assert ok is True, res
+
+
+@pytest.mark.parametrize("world,circuit,K", [(4, "adder_32bit.txt", 2), (8, "adder_32bit.txt", 1), (4, "random:3", 2), (8, "random:4", 3)])
+def test_gate_sharding_four_and_eight_ranks(world, circuit, K):
+    """the same partition / publish / gather code with more ranks than two (the driver's node has eight GPUs): every
+    rank's plan digest agrees (dist.Exchange checks it), every rank ends with every output"""
+    res = _run(1, circuit, K=K, world=world)
+    assert len(res) == world
+    for rank, ok, calls, exchanges in res:
+        assert ok is True, res
+        assert exchanges == calls > 0
+
+
+def test_instance_sharding_eight_ranks():
+    res = _run(0, "adder_32bit.txt", K=8, world=8)
+    for rank, ok, calls, exchanges in res:
+        assert ok is True, res
+        assert calls == 1 and exchanges == 1
+
+
+def test_ranks_with_different_plans_are_told_before_the_first_exchange(monkeypatch):
+    """every rank builds the plan itself from its device's launch capacity; a disagreement used to surface as
+    all-gathers of different sizes.  dist.Exchange compares the plan digests (one MIN / MAX all-reduce) and raises."""
+    monkeypatch.setenv("BCE_TEST_PLAN_MISMATCH", "1")
+    res = _run(1, "adder_32bit.txt", K=5)
+    for rank, ok, _, _ in res:
         assert ok is True, res

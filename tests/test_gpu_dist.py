@@ -42,11 +42,16 @@ def _worker(rank, world, port, shard_mode, K, q, relevel=False):
         c.Clock()
         ok = all(c.Outputs(k)[0] == want for k, (_, want) in enumerate(cases))
         st = c.stats()
-        q.put((rank, ok, st["bootstraps"], st["exchanges"], st["exchanged_cts"]))
+        ident = None
+        if shard_mode == 1:
+            # ciphertext identity: every register this rank computed or received == the single-rank evaluation of the same
+            # input ciphertexts (raises on the first difference)
+            ident = xmod.check_against_single_rank(cc, c, os.path.join(kat.CIRCUITS, "adder_32bit.txt"), False, relevel, K)
+        q.put((rank, ok, st["bootstraps"], st["exchanges"], st["exchanged_cts"], ident))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:
-        q.put((rank, False, repr(e), 0, 0))
+        q.put((rank, False, repr(e), 0, 0, None))
 
 
 def _run(shard_mode, K, world=2, relevel=False):
@@ -65,7 +70,7 @@ def _run(shard_mode, K, world=2, relevel=False):
 def test_encrypted_instance_sharding():
     res = _run(0, K=4)
     total = 0
-    for rank, ok, boots, exchanges, cts in res:
+    for rank, ok, boots, exchanges, cts, _ in res:
         assert ok is True, res
         assert exchanges == 1 and cts == 0          # only the decrypted outputs are gathered
         total += boots
@@ -75,11 +80,14 @@ def test_encrypted_instance_sharding():
 def test_encrypted_gate_sharding_exchanges_boundary_ciphertexts():
     res = _run(1, K=1)
     total = 0
-    for rank, ok, boots, exchanges, cts in res:
+    for rank, ok, boots, exchanges, cts, ident in res:
         assert ok is True, res
         assert exchanges > 0 and cts > 0
         total += boots
+        held, same, per_inst = ident
+        assert held == same and per_inst == 127 + 61 and held >= per_inst // 2      # adder_32bit: 127 AND + 61 XOR registers
     assert total == 310                              # every bootstrap ran on exactly one rank
+    assert sum(r[5][0] for r in res) >= 127 + 61     # together the ranks hold every bootstrapped register
 
 
 def test_encrypted_gate_sharding_on_the_bootstrap_depth_schedule():
@@ -87,11 +95,14 @@ def test_encrypted_gate_sharding_on_the_bootstrap_depth_schedule():
     outputs whose consumers sit on the other rank are exchanged after the step; same sums, every bootstrap on one rank"""
     res = _run(1, K=2, relevel=True)
     total = 0
-    for rank, ok, boots, exchanges, cts in res:
+    for rank, ok, boots, exchanges, cts, ident in res:
         assert ok is True, res
         assert exchanges > 0 and cts > 0
         total += boots
+        held, same, per_inst = ident
+        assert held == same and held >= per_inst      # K = 2: at least half of 2 x 188 registers on each rank
     assert total == 310 * 2
+    assert sum(r[5][0] for r in res) >= 2 * (127 + 61)
 
 
 def test_in_library_rccl_allgather_world_of_one():

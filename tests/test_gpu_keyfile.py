@@ -89,3 +89,56 @@ def test_bad_key_files_are_rejected_with_a_message(bce, orc, tmp_path):
         bce.BinFHEContext(bce.TOY, bce.AP).import_keys_file(good)                          # GINX keys into an AP context
     assert "method" in str(e.value)
     c.import_keys_file(good)                                                                # and the good file still loads
+
+
+@pytest.mark.parametrize("method", ["GINX", "AP"])
+def test_evaluation_form_keys_import_without_a_transform(bce, orc, tmp_path, method):
+    """SURVEY 8(f1), the part testable without OpenFHE: the bootstrapping key as OpenFHE holds it after BTKeyGen --
+    EVALUATION form, bit-reversed order of its Cooley-Tukey transform for the minimal primitive 2N-th root, which is the
+    oracle's (and the engine's) own convention (oracle/binfhe_oracle.c: bo_ntt_forward) -- goes in through
+    bce_import_keys_eval and through a key file with bsk_format = 1, and evaluates bit for bit like the oracle."""
+    import os
+    import stat
+    o = orc.Oracle(orc.TOY, getattr(orc, method))
+    o.keygen(777)
+    N = o.params["N"]
+    bsk_eval = np.concatenate([o.ntt_forward(p) for p in o.bsk().reshape(-1, N)])
+    ca, cb = o.encrypt(1, 0), o.encrypt(1, 1)
+
+    def check(c):
+        c.pool_reserve(4)
+        c.lwe_write([0, 1], np.stack([ca, cb]))
+        c.EvalGates([(bce.NAND, 0, 1, 2), (bce.OR, 0, 1, 3, 1, 0)])
+        out = c.lwe_read([2, 3])
+        assert np.array_equal(out[0], o.eval_bingate(orc.NAND, ca, cb))
+        assert np.array_equal(out[1], o.eval_bingate(orc.OR, o.eval_not(ca), cb))
+
+    c = bce.BinFHEContext(bce.TOY, getattr(bce, method))
+    c.import_keys_eval(o.sk(), o.z(), bsk_eval, o.ksk())
+    check(c)
+    assert np.array_equal(c.export_bsk_eval(), bsk_eval)          # what went in comes out (folded layouts undone)
+    assert np.array_equal(c.export_bsk(), o.bsk())                # and its coefficient form is the oracle's key
+    # the same through a file whose header says "evaluation form"
+    path = str(tmp_path / "eval.bce")
+    write_keyfile(path, o, with_z=False)
+    blob = bytearray(open(path, "rb").read())
+    blob[100:104] = struct.pack("<I", 1)
+    off = (104 + 4 * o.params["n"] + 7) & ~7
+    blob[off:off + 8 * bsk_eval.size] = bsk_eval.astype("<u8").tobytes()
+    open(path, "wb").write(bytes(blob))
+    d = bce.BinFHEContext(bce.TOY, getattr(bce, method))
+    d.import_keys_file(path)
+    check(d)
+    # a context without the ring secret exports a file that says so (has_z = 0), readable by its owner only
+    out_path = str(tmp_path / "reexport.bce")
+    d.export_keys_file(out_path)
+    assert stat.S_IMODE(os.stat(out_path).st_mode) == 0o600
+    hdr = open(out_path, "rb").read(104)
+    assert struct.unpack("<II", hdr[96:104]) == (0, 0)
+    e = bce.BinFHEContext(bce.TOY, getattr(bce, method))
+    e.import_keys_file(out_path)
+    check(e)
+    bad = bytearray(blob); bad[100:104] = struct.pack("<I", 5)
+    open(path, "wb").write(bytes(bad))
+    with pytest.raises(bce.BceError):
+        bce.BinFHEContext(bce.TOY, getattr(bce, method)).import_keys_file(path)

@@ -15,7 +15,9 @@
  *   80      8     bsk_words   (GINX: n*2*R*2*N, AP: n*baseR*dR*R*2*N with R = 2*ceil(log_baseG Q))
  *   88      8     ksk_words   (N*baseKS*dKS*(n+1))
  *   96      4     has_z       (1: the ring secret follows s; it is only needed to RE-export keys, not to evaluate)
- *   100     4     reserved (0)
+ *   100     4     bsk_format  (0: COEFFICIENT representation as described below; 1: EVALUATION representation in the
+ *                                bit-reversed order of OpenFHE's forward transform for the minimal primitive 2N-th root:
+ *                                what DCRTPoly / NativePoly hold after BTKeyGen, dumped without SetFormat)
  *   104     4n    s[n]        LWE secret, entries in {-1, 0, 1}
  *           4N    z[N]        if has_z
  *           pad to a multiple of 8
@@ -32,6 +34,8 @@
 
 #define BCE_KEYFILE_MAGIC "BCEKEYS1"
 #define BCE_KEYFILE_VERSION 1u
+#define BCE_KEYFILE_BSK_COEFFICIENT 0u
+#define BCE_KEYFILE_BSK_EVALUATION 1u
 
 #pragma pack(push, 1)
 typedef struct bce_keyfile_header {
@@ -42,7 +46,7 @@ typedef struct bce_keyfile_header {
     uint64_t bsk_words;
     uint64_t ksk_words;
     uint32_t has_z;
-    uint32_t reserved;
+    uint32_t bsk_format;   /* 0 coefficient, 1 evaluation (OpenFHE order) */
 } bce_keyfile_header; /* 104 bytes */
 #pragma pack(pop)
 
