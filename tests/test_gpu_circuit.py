@@ -100,6 +100,34 @@ def test_bootstrapped_input_mode(bce, toy_cc):
     assert o[0] + 2 * o[1] + 4 * o[2] == 3 + 1
 
 
+def test_input_encryption_defaults_to_bootstrapped_like_the_reference(bce, orc, toy_cc):
+    """cc.Encrypt(sk, bit) at src/circuit.cpp:506 uses OpenFHE v1.0.x's default output mode BOOTSTRAPPED: the driver's
+    default must do the same -- every input ciphertext is Bootstrap() of the fresh encryption, bit for bit the oracle's"""
+    o = orc.Oracle(orc.TOY, orc.GINX)
+    o.keygen(0x0FE5EED)
+    toy_cc.set_encrypt_seed(0x0FE5EED)
+    snap = {}
+    for mode in (None, bce.FRESH):
+        c = bce.Circuit(toy_cc)
+        c.ReadFile(os.path.join(CIRCUITS, "adder_2bit.out"))
+        c.Reset(); c.setEncrypted(True)
+        if mode is None:
+            assert c.getEncryptMode() == bce.BOOTSTRAPPED
+        else:
+            c.setEncryptMode(mode)
+        b0 = toy_cc.timing()["bootstraps"]
+        c.SetInput([[1, 0], [1, 1]])
+        assert toy_cc.timing()["bootstraps"] - b0 == (4 if mode is None else 0)     # one refresh per input bit
+        snap[mode] = toy_cc.lwe_read(np.arange(4, dtype=np.uint32))
+        out = c.Clock()[0]
+        assert out[0] + 2 * out[1] + 4 * out[2] == 1 + 3
+        assert c.stats()["bootstraps"] == 13                                          # Clock's own count is unchanged
+        c.close()
+    toy_cc.set_encrypt_seed(None)
+    for k in range(4):
+        assert np.array_equal(snap[None][k], o.bootstrap(snap[bce.FRESH][k])), "input %d is not Bootstrap(fresh ciphertext)" % k
+
+
 def test_adder_64bit_std128(bce, std_cc, tmp_path):
     """BASELINE config 2: old_bristol adder_64bit, STD128_OPT GINX"""
     out = str(tmp_path / "adder_64bit_FHE.out")
