@@ -966,6 +966,14 @@ __device__ __forceinline__ void split_inverse11(const double* src, double* bufA,
 // 256 bootstraps per launch (profiles/r02_w16_sweep.log): 8 waves 28.1 ms (AP) / 17.0 ms (GINX); 16 waves with one item
 // in flight and nothing requested before the transforms 25.9 / 18.5 ms; every deeper pipeline spills 33..81 registers of
 // the 128 a 1024-thread workgroup leaves each thread and is slower than the 8-wave build.
+// BCE_W16_EARLY (16-wave AP build): both MAC items' key rows are requested BEFORE the forward phase, where the registers
+// are free -- by waves 8..15 at the top of the step (they have no share of the inverse transforms), by waves 0..7 once
+// their digits are written -- and held through the quarter-transforms (48 registers), so that the MAC phase finds them
+// landed instead of exposing the row latency twice per step.  (Requests in front of the inverse transforms, the
+// NPRE knobs below, put 24..48 live registers into the phase that needs all 128: 33..81 spills.)
+#ifndef BCE_W16_EARLY
+#define BCE_W16_EARLY 1
+#endif
 #ifndef BCE_W16_NBUF_AP
 #define BCE_W16_NBUF_AP 1
 #define BCE_W16_NPRE_AP 0
@@ -1081,7 +1089,8 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
         // key rows: same software pipeline as the integer kernel
         constexpr u32 ITEMS = (2u * (N / 2) + T - 1) / T;
         constexpr u32 ROWS = AP ? R : 2 * R;
-        constexpr u32 NBUF = NBUF_, NPRE = NPRE_;
+        constexpr bool EARLY = W16 && AP && FOLD && (BCE_W16_EARLY != 0);   // (the plain-key build has six rows to transform: no room)
+        constexpr u32 NBUF = EARLY ? ITEMS : NBUF_, NPRE = EARLY ? ITEMS : NPRE_;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<double*>(bk), 0, (int)((AP ? 1 : 2) * rgsw * sizeof(double)), 0x00020000);
         double2 kb[NBUF][ROWS];
@@ -1102,10 +1111,12 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
                 }
             }
         };
-        if constexpr (NPRE >= 1) request(std::integral_constant<u32, 0>{});
-        if constexpr (NPRE >= 2) request(std::integral_constant<u32, 1>{});
+        if constexpr (!EARLY && NPRE >= 1) request(std::integral_constant<u32, 0>{});
+        if constexpr (!EARLY && NPRE >= 2) request(std::integral_constant<u32, 1>{});
         if (W16 && tid_v >= 512u) {
-            // waves 8..15 have no share of the inverse transforms: they only keep the barrier count
+            // waves 8..15 have no share of the inverse transforms: they only keep the barrier count (and, EARLY, pull
+            // their key rows while their registers are free)
+            if constexpr (EARLY) for_each_index(request, std::make_integer_sequence<u32, ITEMS>{});
 #pragma unroll
             for (int b = 0; b < INV_BARRIERS + 1; ++b) block_sync_lds();
         } else if constexpr (SPLIT) {
@@ -1156,6 +1167,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
 #pragma unroll
                 for (int r = 0; r < 8; ++r) dct[(2 * l + c) * NP + phys(((u32)r << 8) | t)] = v[r];
             }
+            if constexpr (EARLY) for_each_index(request, std::make_integer_sequence<u32, ITEMS>{});
         } else if (wave < 2) {
             double x[E];
             ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, Tw{tw, nullptr}, lane_v, Q, ninv, x);
