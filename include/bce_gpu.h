@@ -201,8 +201,9 @@ int bce_dag_set_limits(bce_ctx*, int workgroups_per_cu, int placement, uint32_t 
 /* counters of the last finished bce_dag_run (after a synchronising call): out[0] bootstraps completed,
  * out[1] claims a half-busy compute unit delayed in favour of an idle one, out[2] abort code (0 = none),
  * out[3] workgroups per CU the run used, out[4] / out[5] 100 MHz ticks summed over all workgroups between claiming
- * a bootstrap and releasing its consumers / spent looking for a bootstrap they then got */
-int bce_dag_last_run(bce_ctx*, uint64_t out[6]);
+ * a bootstrap and releasing its consumers / spent looking for a bootstrap they then got, out[6] ticks spent waiting at the
+ * XCD start gates (inside out[4]) */
+int bce_dag_last_run(bce_ctx*, uint64_t out[7]);
 /* test hook: task `t` of the DAG waits for one producer more than it has, so it never becomes ready and the run
  * stalls (exercises the bounded-spin exit) */
 int bce_dag_debug_block_task(bce_dag*, uint32_t t);

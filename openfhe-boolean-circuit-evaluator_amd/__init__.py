@@ -335,12 +335,13 @@ class BinFHEContext:
         self._ck(self._L.bce_dag_set_limits(self.h, int(workgroups_per_cu), int(placement), int(lazy_us), int(stall_ms)))
 
     def dag_last_run(self):
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 7)()
         self._ck(self._L.bce_dag_last_run(self.h, out))
         d = {"done": int(out[0]), "lazy_waits": int(out[1]), "abort": int(out[2]), "workgroups_per_cu": int(out[3])}
         if out[0]:
             d["ms_per_bootstrap"] = round(out[4] / out[0] / 1e5, 4)        # 100 MHz ticks
             d["wait_ms_per_bootstrap"] = round(out[5] / out[0] / 1e5, 4)
+            d["gate_ms_per_bootstrap"] = round(out[6] / out[0] / 1e5, 4)
         return d
 
     def dag_debug_block_task(self, dag, t):

@@ -120,7 +120,7 @@ struct bce_ctx {
     DevParams* d_P = nullptr;
     int dag_wg_per_cu = 0, dag_placement = 1;
     uint32_t dag_lazy_us = 20, dag_stall_ms = 4000;
-    struct DagStatus { uint32_t abort, done, lazy_waits, pad; uint64_t busy_ticks, wait_ticks; };
+    struct DagStatus { uint32_t abort, done, lazy_waits, pad; uint64_t busy_ticks, wait_ticks, gate_ticks; };
     static constexpr int kDagRuns = 32;
     DagStatus* h_dag_status = nullptr;        // pinned, kDagRuns entries
     struct DagStage { DevParams P; DagParams D; };
@@ -128,7 +128,7 @@ struct bce_ctx {
     uint64_t dag_expected[kDagRuns] = {0};
     int dag_wps_used[kDagRuns] = {0};
     int dag_pending = 0;
-    uint64_t dag_last[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t dag_last[7] = {0, 0, 0, 0, 0, 0, 0};
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -520,7 +520,7 @@ int check_dag_runs(bce_ctx* c) {
     for (int i = 0; i < c->dag_pending; ++i) {
         const bce_ctx::DagStatus& st = c->h_dag_status[i];
         c->dag_last[0] = st.done; c->dag_last[1] = st.lazy_waits; c->dag_last[2] = st.abort; c->dag_last[3] = (u64)c->dag_wps_used[i] / 2;
-        c->dag_last[4] = st.busy_ticks; c->dag_last[5] = st.wait_ticks;
+        c->dag_last[4] = st.busy_ticks; c->dag_last[5] = st.wait_ticks; c->dag_last[6] = st.gate_ticks;
         if (st.abort != 0 || st.done != c->dag_expected[i])
             rc = c->fail(BCE_ERR_STATE, "bce_dag_run: the device scheduler gave up (abort code %u, %u of %llu bootstraps completed, no progress for %u ms)",
                          st.abort, st.done, (unsigned long long)c->dag_expected[i], c->dag_stall_ms);
@@ -1027,9 +1027,9 @@ int bce_dag_set_limits(bce_ctx* c, int workgroups_per_cu, int placement, uint32_
     return BCE_OK;
 }
 
-int bce_dag_last_run(bce_ctx* c, uint64_t out[6]) {
+int bce_dag_last_run(bce_ctx* c, uint64_t out[7]) {
     if (!c || !out) return BCE_ERR_ARG;
-    for (int i = 0; i < 6; ++i) out[i] = c->dag_last[i];
+    for (int i = 0; i < 7; ++i) out[i] = c->dag_last[i];
     return BCE_OK;
 }
 
@@ -1164,6 +1164,10 @@ int bce_dag_run(bce_ctx* c, bce_dag* g, uint32_t instances, uint32_t slot_stride
     D.lazy_ticks = c->dag_lazy_us * 100u;                     // s_memrealtime: 100 MHz
     D.stall_ticks = c->dag_stall_ms * 100000u;
     D.policy = c->dag_placement ? 1u : 0u;
+    D.gate_ticks = 15000;        // 150 us: the finish times of bootstraps that started together spread less than that
+    D.gate_backlog = 64;
+    if (const char* e = std::getenv("BCE_DAG_GATE_US")) D.gate_ticks = (u32)std::atoi(e) * 100u;
+    if (const char* e = std::getenv("BCE_DAG_GATE_BACKLOG")) D.gate_backlog = (u32)std::atoi(e);
     // one or two workgroups per CU: two run 512 bootstraps per ~3.1 ms, one runs 256 per ~1.9 ms -- with less work per
     // dependency level than the CUs can hold alone, the shorter bootstrap wins
     int wps = c->dag_wg_per_cu == 1 ? 2 : 4;
@@ -1172,6 +1176,8 @@ int bce_dag_run(bce_ctx* c, bce_dag* g, uint32_t instances, uint32_t slot_stride
     if (const char* e = std::getenv("BCE_DAG_PLACE")) D.policy = e[0] == '0' ? 0u : 1u;
     const char* dbg = std::getenv("BCE_DAG_DEBUG");   // development: 'r' = re-arm only, 'd' = dry run (no bootstraps)
     if (dbg && dbg[0] == 'd') D.policy |= 2u;
+    // the XCD start gate pays where two workgroups per CU share the L2 in the saturated regime (development knob BCE_DAG_GATE=0 / 1)
+    { const char* e = std::getenv("BCE_DAG_GATE"); if (e ? e[0] != '0' : wps == 4) D.policy |= 4u; }
     const u32 grid = c->P.cu_count * (wps == 2 ? 1u : 2u);
     // parameter blocks reach the device in stream order (an earlier run may still be reading the previous ones) from
     // pinned staging entries that stay untouched until the next synchronisation

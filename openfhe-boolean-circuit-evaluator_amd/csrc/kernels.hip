@@ -1421,7 +1421,8 @@ __device__ __forceinline__ u32 dag_add(u32* p, u32 v) { return __hip_atomic_fetc
 // the head instead makes every idle workgroup retry against every other one: measured 5.6 us per claim, serialised,
 // with 512 workgroups (180 k claims/s for the whole chip -- the scheduler itself was the bottleneck).
 template <typename DT>
-__device__ __forceinline__ u32 dag_acquire(const DT& D, const u32* my_busy, bool first_on_cu) {
+__device__ __forceinline__ u32 dag_acquire(const DT& D, const u32* my_busy, bool first_on_cu, bool& deep) {
+    deep = false;
     u32* const ctl = D.ctl;
     u32 last_h[kDagQueues];
     u64 seen[kDagQueues];
@@ -1464,6 +1465,12 @@ __device__ __forceinline__ u32 dag_acquire(const DT& D, const u32* my_busy, bool
             pick = q;
         }
         if (pick != kDagQueues) {
+            {   // "saturated" = ready entries over all classes (an urgent class is short by nature)
+                u32 ready = 0;
+#pragma unroll
+                for (u32 q = 0; q < kDagQueues; ++q) { const u32 b = tl[q] - hd[q]; if ((int)b > 0) ready += b; }
+                deep = ready >= D.gate_backlog;
+            }
             const u32 t = dag_add(ctl + pick, 1u);
             if (t < D.qcap[pick]) {
                 const u32* const entry = D.slots[pick] + t;
@@ -1492,6 +1499,69 @@ __device__ __forceinline__ u32 dag_acquire(const DT& D, const u32* my_busy, bool
         // idle: poll gently (the wake-up delay is microseconds on a bootstrap of milliseconds; hundreds of workgroups
         // re-reading the control line every microsecond slow the ones that work)
         if (spin < 4) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(127);
+    }
+}
+// ---- XCD start gate ------------------------------------------------------------------------------------------------
+// A step of a bootstrap streams 128 KiB of key rows; the 64 workgroups of an XCD share one 4 MiB L2.  Started together
+// (a per-frontier launch does that) they walk the key in lock-step and every row is fetched into that L2 once; left to
+// drift -- each workgroup takes its next bootstrap when it happens to finish -- every workgroup streams the whole 62.8 MiB
+// key through the L2 by itself: FETCH_SIZE per bootstrap x3, each bootstrap 3.4-3.7 ms instead of 3.1
+// (profiles/r03_dataflow_kernel.log).  The gate restores the lock-step where it pays, in the saturated regime (a claim
+// made while >= gate_backlog entries were ready): the workgroups of an XCD start their bootstraps in COHORTS.
+//   gate word (u64 per XCD): [generation : 32 | waiting : 32].  A workgroup arrives (waiting++), remembers the generation
+//   it waits for, and starts when the generation moves on.  Whoever opens the gate (CAS generation + 1, waiting = 0)
+//   records the cohort's size; a member that comes back after its bootstrap counts itself into arrived[old generation],
+//   and the member that completes the count opens the gate for everybody waiting -- bootstraps that started together end
+//   within tens of microseconds of each other, so a cohort re-forms without waiting for anybody else's cohort, and
+//   cohorts whose ends overlap merge.  Workgroups without a cohort (first bootstrap, or the last one ran ungated) gather
+//   for gate_ticks / 8; nobody waits longer than gate_ticks.  A member that leaves (ungated claim, exit) resigns, so that
+//   its cohort's count still completes.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+constexpr u32 kDagNoCohort = 0xFFFFFFFFu;
+// counts this workgroup into its old cohort; true when that completes the cohort
+__device__ __forceinline__ bool dag_cohort_arrive(u32* ctl, u32 xcc, u32 prev) {
+    u32* const c = ctl + kDagCohort + (xcc * kDagCohortRing + (prev % kDagCohortRing)) * 2u;
+    return dag_add(c + 1, 1u) + 1u >= dag_ld(c);
+}
+__device__ __forceinline__ bool dag_gate_open(u32* ctl, u32 xcc, unsigned long long seen) {
+    gu64* const g = (gu64*)(ctl + kDagGate + 32u * xcc);
+    const u32 gen = (u32)(seen >> 32);
+    if (!__hip_atomic_compare_exchange_strong(g, &seen, (unsigned long long)(gen + 1u) << 32, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT))
+        return false;
+    u32* const c = ctl + kDagCohort + (xcc * kDagCohortRing + (gen % kDagCohortRing)) * 2u;
+    dag_st(c + 1, 0u);                 // members come back milliseconds later
+    dag_st(c, (u32)seen);              // size of the cohort that starts now
+    return true;
+}
+// returns the generation (= cohort) this bootstrap starts in
+__device__ __forceinline__ u32 dag_gate_enter(u32* ctl, u32 xcc, u32 prev, u32 gate_ticks) {
+    gu64* const g = (gu64*)(ctl + kDagGate + 32u * xcc);
+    const u64 t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long old = __hip_atomic_fetch_add(g, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 gen = (u32)(old >> 32);
+    const bool opener = prev != kDagNoCohort && dag_cohort_arrive(ctl, xcc, prev);
+    const u32 limit = prev == kDagNoCohort ? gate_ticks / 8u : gate_ticks;
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((u32)(v >> 32) != gen) break;                                  // opened for this group
+        if (opener || __builtin_amdgcn_s_memrealtime() - t0 > limit) {
+            if (dag_gate_open(ctl, xcc, v)) break;
+            continue;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __hip_atomic_fetch_add((gu64*)(ctl + kDagGateWaits), (unsigned long long)(__builtin_amdgcn_s_memrealtime() - t0), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    return gen;
+}
+// a member leaves its cohort without coming back to the gate
+__device__ __forceinline__ void dag_gate_resign(u32* ctl, u32 xcc, u32 prev) {
+    if (!dag_cohort_arrive(ctl, xcc, prev)) return;
+    gu64* const g = (gu64*)(ctl + kDagGate + 32u * xcc);
+    for (int tries = 0; tries < 4; ++tries) {
+        const unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((u32)v == 0 || dag_gate_open(ctl, xcc, v)) return;            // nobody waits / opened
     }
 }
 }  // namespace
@@ -1531,8 +1601,8 @@ __device__ __forceinline__ C* as_constant(const S* p) {
 template <int WPS, bool AP, bool FOLD>
 __global__ __launch_bounds__(512, WPS) void k_bootstrap_dag(const DevParams* Pp, const DagParams* Dp) {
     extern __shared__ __align__(16) u32 smem[];
-    // four words in front of the LDS layout of lat_bootstrap: [0] the item the workgroup runs next, [1] "first workgroup
-    // of its CU", [2] the CU's key, [3] when the item was claimed
+    // eight words in front of the LDS layout of lat_bootstrap: [0] the item the workgroup runs next, [1] "first workgroup
+    // of its CU", [2] the CU's key, [3] when the item was claimed, [4] the cohort (gate generation) its last gated bootstrap started in
     u32* const mbox = smem;
     if (threadIdx.x == 0) {
         // which CU this workgroup sits on: HW_ID[15:8] = (SE, SH, CU), XCC_ID[3:0]
@@ -1542,6 +1612,7 @@ __global__ __launch_bounds__(512, WPS) void k_bootstrap_dag(const DevParams* Pp,
         if (arrival == 0) dag_add(Dp->ctl + kDagIdleCus, 1u);
         mbox[1] = arrival == 0;   // the CU's first workgroup claims eagerly, later arrivals yield to idle CUs
         mbox[2] = key;
+        mbox[4] = kDagNoCohort;
     }
     for (;;) {
         // The thread index is made opaque in every iteration and at every use: a comparison the optimiser can prove
@@ -1555,15 +1626,21 @@ __global__ __launch_bounds__(512, WPS) void k_bootstrap_dag(const DevParams* Pp,
             ConstDagParams& D = *as_constant<ConstDagParams>(Dp);
             u32* const my_busy = D.ctl + kDagCuBusy + mbox[2];
             const u64 t_in = __builtin_amdgcn_s_memrealtime();
-            const u32 it = dag_acquire(D, my_busy, mbox[1] != 0);
+            bool deep;
+            const u32 it = dag_acquire(D, my_busy, mbox[1] != 0, deep);
             if (it != kDagExit) {
                 const u64 t_got = __builtin_amdgcn_s_memrealtime();
                 __hip_atomic_fetch_add((__attribute__((address_space(1))) u64*)(D.ctl + kDagWaitTicks), t_got - t_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 mbox[3] = (u32)t_got;
                 if (dag_add(my_busy, 1u) == 0) __hip_atomic_fetch_sub((gu32*)(D.ctl + kDagIdleCus), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool gated = (D.policy & 4u) && deep;
+                const u32 prev = mbox[4];
+                if (gated) mbox[4] = dag_gate_enter(D.ctl, mbox[2] >> 8, prev, D.gate_ticks);
+                else if (prev != kDagNoCohort) { dag_gate_resign(D.ctl, mbox[2] >> 8, prev); mbox[4] = kDagNoCohort; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            else if (mbox[4] != kDagNoCohort) { dag_gate_resign(D.ctl, mbox[2] >> 8, mbox[4]); mbox[4] = kDagNoCohort; }
             mbox[0] = it;
         }
         __syncthreads();
@@ -1574,7 +1651,7 @@ __global__ __launch_bounds__(512, WPS) void k_bootstrap_dag(const DevParams* Pp,
             const u32 nt = D.n_tasks, k = item / nt, t = item - k * nt;
             // policy bit 1 (development): walk the DAG without running the bootstraps -- the scheduler's own time
             if (!(D.policy & 2u))
-            lat_bootstrap<4, WPS, AP, true, FOLD, true>(*as_constant<ConstDevParams>(Pp), D.tasks[t], D.slot_base + k * D.slot_stride, 0, smem + 4,
+            lat_bootstrap<4, WPS, AP, true, FOLD, true>(*as_constant<ConstDevParams>(Pp), D.tasks[t], D.slot_base + k * D.slot_stride, 0, smem + 8,
                                                        nullptr, nullptr, nullptr);
         }
         // publish: every storing wave drains, barrier, one wave releases at agent scope, then the counters
@@ -1604,6 +1681,7 @@ __global__ __launch_bounds__(512, WPS) void k_bootstrap_dag(const DevParams* Pp,
                 dag_add(D.ctl + kDagDone, 1u);
                 if (__hip_atomic_fetch_sub((gu32*)(D.ctl + kDagCuBusy + mbox[2]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u)
                     dag_add(D.ctl + kDagIdleCus, 1u);
+
             }
         }
     }
@@ -1625,7 +1703,7 @@ hipError_t launch_bootstrap_dag(const DevParams& P, const DevParams* d_P, const 
     DagKernel k;
     if (P.fold) k = ap ? (x1 ? k_bootstrap_dag<2, true, true> : k_bootstrap_dag<4, true, true>) : (x1 ? k_bootstrap_dag<2, false, true> : k_bootstrap_dag<4, false, true>);
     else k = ap ? (x1 ? k_bootstrap_dag<2, true, false> : k_bootstrap_dag<4, true, false>) : (x1 ? k_bootstrap_dag<2, false, false> : k_bootstrap_dag<4, false, false>);
-    const size_t lds = blind_rotate_lat_lds_bytes(P) + 16;   // + the mailbox words in front
+    const size_t lds = blind_rotate_lat_lds_bytes(P) + 32;   // + the mailbox words in front
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, d_P, d_params);

@@ -84,7 +84,11 @@ constexpr u32 kDagWaitTicks = kDagAbort + 6;               // u64: ticks workgro
 constexpr u32 kDagIdleCus = 8;                             // compute units none of whose workgroups runs a bootstrap (same line as heads / tails)
 constexpr u32 kDagCuArrive = kDagAbort + 32;               // [kDagCuKeys] workgroups that announced themselves per CU
 constexpr u32 kDagCuBusy = kDagCuArrive + kDagCuKeys;      // [kDagCuKeys] workgroups running a bootstrap per CU
-constexpr u32 kDagCtlWords = kDagCuBusy + kDagCuKeys;
+constexpr u32 kDagGate = kDagCuBusy + kDagCuKeys;          // [16 XCC ids] x 32 words: word pair 0 = the XCD's start gate (u64)
+constexpr u32 kDagCohortRing = 64;                         // generations of an XCD's gate whose (size, arrived) pairs are kept
+constexpr u32 kDagCohort = kDagGate + 16 * 32;             // [16 XCC ids][kDagCohortRing] x {size, arrived}
+constexpr u32 kDagGateWaits = kDagAbort + 8;               // u64: ticks workgroups waited at their XCD's start gate
+constexpr u32 kDagCtlWords = kDagCohort + 16 * kDagCohortRing * 2;
 struct DagParams {
     const bce_gate_desc* tasks;   // [n_tasks] topological order, SSA slots
     const u32* cons_off;          // [n_tasks + 1]
@@ -100,7 +104,10 @@ struct DagParams {
     u32 n_tasks, instances, slot_stride, slot_base;   // instance k: slot numbers + slot_base + k * slot_stride
     u32 lazy_ticks;               // 100 MHz ticks a workgroup on a half-busy CU leaves a lone ready item to an idle CU
     u32 stall_ticks;              // 100 MHz ticks without any push after which a poller sets the abort word
-    u32 policy;                   // bit 0: placement-aware claims (idle CUs first)
+    u32 policy;                   // bit 0: placement-aware claims (idle CUs first); bit 1: dry run (development);
+                                  // bit 2: workgroups of one XCD that claimed from a deep queue start their bootstraps together
+    u32 gate_ticks;               // longest wait at the XCD start gate (100 MHz ticks)
+    u32 gate_backlog;             // queue depth at claim time from which a bootstrap goes through the gate
 };
 // rearm = reset counters / queues for one evaluation; then the persistent launch.  wps = 2: one workgroup per CU
 // (256-register build), 4: two per CU.  grid = resident workgroups (never more).
