@@ -1,5 +1,5 @@
 #!/bin/bash
-# Counters of ONE saturated launch of the BASELINE config-5 kernel (STD192, AP, 256 bootstraps = one per CU):
+# Counters of ONE saturated launch of the BASELINE config-5 kernel (STD192, AP; CFG5_BATCH bootstraps, default 1024 = four rounds of one workgroup per CU):
 #   tools/collect_evidence_cfg5.sh <tag>   -> gpurun_out/<tag>/  (run from the repo root on the GPU box)
 # kernel time (rocprofv3 kernel stats), executed VALU wave-instructions (SQ pass), fabric traffic (FETCH_SIZE / WRITE_SIZE
 # in separate passes).  Post-processing into profiles/: tools/make_profiles_cfg5.sh.
@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-QP="python3 $R/tools/quick_perf_cfg.py STD192 AP 256"
+QP="python3 $R/tools/quick_perf_cfg.py STD192 AP ${CFG5_BATCH:-1024}"
 $QP > "$OUT/quick_perf.log" 2>&1
 cat "$OUT/quick_perf.log"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $QP > "$OUT/stats.out" 2> "$OUT/stats.err"
