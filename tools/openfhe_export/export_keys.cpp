@@ -17,6 +17,9 @@
 //
 // build (on a machine with OpenFHE >= 1.0.1 installed):
 //   cmake -S tools/openfhe_export -B build_export && cmake --build build_export
+// Environment: BCE_EXPORT_EVALUATION=1 dumps the bootstrapping key as OpenFHE holds it (EVALUATION representation, no
+// SetFormat pass over the key) and marks the file bsk_format = 1; the engine imports that without a transform
+// (bce_import_keys_eval): the engine's evaluation order is OpenFHE's (bit-reversed CT order, minimal primitive 2N-th root).
 // usage:
 //   export_keys <TOY|STD128_OPT|...> <AP|GINX> <keys.bce> [<ciphertexts.bin> <bit> ...]
 //     generates a context + keys exactly like the reference's Circuit constructor, writes the keys, and
@@ -34,6 +37,8 @@
 
 #include "bce_keyfile.h"
 
+static bool g_evaluation_form = false;   // BCE_EXPORT_EVALUATION=1
+
 using namespace lbcrypto;
 
 namespace {
@@ -49,7 +54,7 @@ void put_rgsw(FILE* f, const RingGSWEvalKey& ek, uint32_t N) {
     std::vector<uint64_t> words(N);
     for (const auto& row : ek->GetElements())
         for (NativePoly poly : row) {  // by value: SetFormat on a copy
-            poly.SetFormat(Format::COEFFICIENT);
+            if (!g_evaluation_form) poly.SetFormat(Format::COEFFICIENT);
             for (uint32_t k = 0; k < N; ++k) words[k] = poly[k].ConvertToInt();
             put(f, words.data(), N * sizeof(uint64_t));
         }
@@ -58,6 +63,7 @@ void put_rgsw(FILE* f, const RingGSWEvalKey& ek, uint32_t N) {
 }  // namespace
 
 int main(int argc, char** argv) {
+    { const char* e = std::getenv("BCE_EXPORT_EVALUATION"); g_evaluation_form = e && e[0] == '1'; }
     if (argc < 4) {
         std::fprintf(stderr, "usage: %s <paramset> <AP|GINX> <keys.bce> [<cts.bin> <bit> ...]\n", argv[0]);
         return 2;
@@ -92,6 +98,7 @@ int main(int argc, char** argv) {
     h.bsk_words = (method == AP ? (uint64_t)n * baseR * dR : (uint64_t)n * 2) * R * 2 * N;
     h.ksk_words = (uint64_t)N * baseKS * dKS * (n + 1);
     h.has_z = 0;  // BTKeyGen does not keep the ring secret; evaluation does not need it
+    h.bsk_format = g_evaluation_form ? BCE_KEYFILE_BSK_EVALUATION : BCE_KEYFILE_BSK_COEFFICIENT;
 
     FILE* f = std::fopen(argv[3], "wb");
     if (!f) throw std::runtime_error("cannot open the key file for writing");
