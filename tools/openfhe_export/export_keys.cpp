@@ -25,8 +25,10 @@
 //     generates a context + keys exactly like the reference's Circuit constructor, writes the keys, and
 //     optionally encrypts the given bits and appends them as u64[n+1] words each (a_0..a_{n-1}, b) mod q,
 //     the layout bce_lwe_write() takes.
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <stdexcept>
