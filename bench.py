@@ -186,7 +186,7 @@ def main():
     ap.add_argument("--no-block-latency", action="store_true",
                     help="skip the K = 1 single-block leg (profiled runs: keeps the kernel statistics to the timed workload)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--gates-timeout", type=int, default=150, help="N > 1: watchdog (s) over the secondary run and the teardown")
+    ap.add_argument("--gates-timeout", type=int, default=300, help="N > 1: watchdog (s) over the secondary run and the teardown")
     ap.add_argument("--gates-steps", type=int, default=2, help="N > 1: timed steps of the secondary gate-sharded run (0 = skip)")
     args = ap.parse_args()
     if args.config is not None:

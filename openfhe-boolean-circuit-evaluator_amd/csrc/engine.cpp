@@ -1165,7 +1165,7 @@ int bce_dag_run(bce_ctx* c, bce_dag* g, uint32_t instances, uint32_t slot_stride
     D.stall_ticks = c->dag_stall_ms * 100000u;
     D.policy = c->dag_placement ? 1u : 0u;
     D.gate_ticks = 15000;        // 150 us: the finish times of bootstraps that started together spread less than that
-    D.gate_backlog = 64;
+    D.gate_backlog = 8;          // (64 / 16 / 4 / 1: AES K = 8 at 150 / 153 / 154 / 155 k; with the classes below 157 k, profiles/r03_dataflow_vs_steps.jsonl)
     if (const char* e = std::getenv("BCE_DAG_GATE_US")) D.gate_ticks = (u32)std::atoi(e) * 100u;
     if (const char* e = std::getenv("BCE_DAG_GATE_BACKLOG")) D.gate_backlog = (u32)std::atoi(e);
     // one or two workgroups per CU: two run 512 bootstraps per ~3.1 ms, one runs 256 per ~1.9 ms -- with less work per
