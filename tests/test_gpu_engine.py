@@ -251,6 +251,9 @@ def test_errors_are_reported_not_thrown(bce):
     with pytest.raises(bce.BceError) as e:
         bce.BinFHEContext(bce.STD256, bce.GINX)   # N = 2048 with 4 gadget digits: not instantiated
     assert e.value.code == bce.ERR_UNSUPPORTED
+    with pytest.raises(bce.BceError) as e:           # ring modulus of 40 bits or more (1099511630849 = 1 mod 1024, prime): no kernel
+        bce.BinFHEContext(method=bce.GINX, custom=(16, 512, 512, 1099511630849, 1 << 14, 128, 1 << 14, 23))
+    assert e.value.code == bce.ERR_UNSUPPORTED
 
 
 # ---- AP (DM) method: SURVEY 8(a7) -------------------------------------------------------------
