@@ -19,13 +19,13 @@ br = next(k for k in raw if "blind_rotate" in k)
 tails = {k: v for k, v in raw.items() if "k_tail" in k}
 label = "k_blind_rotate_lat<4,4> (split transform, 2 workgroups/CU)" if br.startswith("void bce::k_blind_rotate_lat<4, 4, false") else br
 out = {"kernel": br, "bench_kernel": label,
-       "workload": "AES-expanded.txt STD128_OPT GINX instances_per_gpu=32, bootstrap-depth schedule (bench.py default), 1 step",
+       "workload": "AES-expanded.txt STD128_OPT GINX instances_per_gpu=32, bootstrap-depth schedule (bench.py default; inputs encrypted FRESH so that the kernel statistics hold the timed launches only), 1 step",
        "instances_per_gpu": 32, "relevel": True,
        "hbm_bytes_per_launch": raw[br]["hbm_bytes_per_launch"], "launches": raw[br]["launches"],
        "fetch_kib_raw_per_launch": raw[br]["fetch_kib_raw_per_launch"], "write_kib_per_launch": raw[br]["write_kib_per_launch"],
        "tail_hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] for v in tails.values()),
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 1 --warmup 0 "
-                 "--no-cpu-baseline --no-block-latency` (tools/collect_evidence.sh); FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as is; "
+                 "--no-cpu-baseline --no-block-latency --fresh-inputs` (tools/collect_evidence.sh); FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE as is; "
                  "KiB -> bytes; Infinity-Cache hits are included in these fabric-side counters",
        "tail_kernels": tails}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
