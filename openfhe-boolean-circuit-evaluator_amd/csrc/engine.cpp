@@ -568,7 +568,7 @@ int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances,
         int kid = BCE_BR_WORD64;
         bool tail_fused = false;
         hipEventRecord(e0.a, c->stream);
-        if (c->is64) HIP_TRY(c, launch_blind_rotate64(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u64*>(c->d_acc), c->stream));
+        if (c->is64) HIP_TRY(c, launch_blind_rotate64(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u64*>(c->d_acc), c->stream, d_lweN, d_ks, &tail_fused));
         else HIP_TRY(c, launch_blind_rotate(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u32*>(c->d_acc), c->stream, &kid, d_lweN, d_ks, &tail_fused));
         hipEventRecord(e0.b, c->stream);
         e0.kind = kid;

@@ -137,8 +137,10 @@ hipError_t launch_tail(const DevParams& P, const bce_gate_desc* d_descs, u32 n_d
 
 // 64-bit-modulus counterparts (kernels64.hip)
 size_t blind_rotate64_lds_bytes(const DevParams& P);
+// *tail_fused (optional) is set when the launched kernel also ran the tail (then dbg_lweN / dbg_ks are its debug outputs)
 hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances,
-                                 u32 slot_stride, u64* acc_out, hipStream_t s);
+                                 u32 slot_stride, u64* acc_out, hipStream_t s, u32* dbg_lweN = nullptr, u32* dbg_ks = nullptr,
+                                 bool* tail_fused = nullptr);
 hipError_t launch_ntt_batch64(const DevParams& P, u64* polys, u32 count, int inverse, hipStream_t s);
 // key words u64 <-> IEEE double in place (layout of the double-precision formulation)
 hipError_t launch_words_u64_f64(u64* words, size_t count, int to_double, hipStream_t s);

@@ -16,6 +16,7 @@
 #include "phase_prof.hpp"
 
 namespace bce {
+#include "fused_tail.hpp"
 #ifdef BCE_PHASE_PROF
 __device__ unsigned long long g_phase_prof64[BCE_PROF_WAVES * BCE_PROF_SLOTS];
 #define BCE_PROF_ARRAY ::bce::g_phase_prof64
@@ -221,7 +222,7 @@ __device__ __forceinline__ u32 gate_const(u32 op, u32 q) {
 // the defaults are the deepest that compile without scratch at N = 2048 (GINX items carry two keys' rows)
 template <int LOGN, int DG, bool AP, u32 NBUF_ = (AP ? 3 : 2), u32 NPRE_ = (AP ? 2 : 1)>
 __global__ __launch_bounds__(128 * DG) void k_blind_rotate64(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
-                                                              u32 slot_stride, u64* __restrict__ acc_out) {
+                                                              u32 slot_stride, u64* __restrict__ acc_out, u32* /*dbg_lweN: no fused tail*/, u32* /*dbg_ks*/) {
     using C = Cfg<LOGN>;
     constexpr int N = C::N, NP = C::NP, E = C::E;
     constexpr u32 R = 2 * DG, T = 64 * R;
@@ -986,11 +987,16 @@ __device__ __forceinline__ void split_inverse11(const double* src, double* bufA,
 // forward transforms per step instead of six = eight half-transforms, one per wave (8-wave build), or sixteen quarter-
 // transforms, one per wave (16-wave build).  The accumulator is double-buffered between `acc` and digit rows 0, 1; the inverse transform's exchange buffers
 // move to digit rows 2..5.
-template <int LOGN, int DG, bool AP, bool SPLIT = false, bool W16 = false, bool FOLD = false,
+// FUSE (16-wave build): the tail of EvalBinGate runs in this kernel's epilogue (fused_tail.hpp) -- the coefficient-form
+// accumulator goes to LDS as u64 words, all 1,024 threads extract, switch the modulus, gather the N dKS key-switching rows
+// (33.6 MB for STD192) and write the refreshed ciphertext to the pool; no tail kernels, no accumulator round trip through HBM.
+template <int LOGN, int DG, bool AP, bool SPLIT = false, bool W16 = false, bool FOLD = false, bool FUSE = false,
           u32 NBUF_ = (W16 ? (AP ? BCE_W16_NBUF_AP : BCE_W16_NBUF_GINX) : (AP ? 3 : 2)),
           u32 NPRE_ = (W16 ? (AP ? BCE_W16_NPRE_AP : BCE_W16_NPRE_GINX) : (AP ? 2 : 1))>
 __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind_rotate64d(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
-                                                               u32 slot_stride, u64* __restrict__ acc_out) {
+                                                               u32 slot_stride, u64* __restrict__ acc_out,
+                                                               u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
+    static_assert(!FUSE || (W16 && SPLIT), "fused tail: 16-wave build");
     using C = Cfg<LOGN>;
     constexpr int N = C::N, NP = C::NP, E = C::E;
     constexpr u32 R = 2 * DG, T = W16 ? 1024 : (SPLIT ? 512 : 64 * R);
@@ -1277,12 +1283,15 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
         double x[8];
         split_inverse11(cur + c * NP, dct + (XA + c) * NP, dct + (XB + c) * NP, twa, t, Q, x);
         u64* out = acc_out + ((size_t)blockIdx.x * 2 + c) * N;
+        u64* coef = reinterpret_cast<u64*>(acc);   // FUSE: [2][N] u64 in the accumulator's own rows (dead: `cur` was read by pass 0)
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const double y = modmul_q(x[r], ninv.x, ninv.y, Q);
             const double v = y < 0.0 ? y + Q : y;
             const double hi = floor(v * (1.0 / 4294967296.0));
-            out[((u32)r << 8) | t] = ((u64)(u32)hi << 32) | (u64)(u32)fma(-hi, 4294967296.0, v);
+            const u64 wv = ((u64)(u32)hi << 32) | (u64)(u32)fma(-hi, 4294967296.0, v);
+            out[((u32)r << 8) | t] = wv;
+            if constexpr (FUSE) coef[c * N + (((u32)r << 8) | t)] = wv;
         }
     } else if (wave < 2) {
         double x[E];
@@ -1295,6 +1304,25 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
             out[((u32)r << 6) | lane] = ((u64)(u32)hi << 32) | (u64)(u32)fma(-hi, 4294967296.0, v);
         }
     }
+    if constexpr (FUSE) {
+        // FOLD: if the last step left the evaluation-form accumulator in digit rows 0, 1 (`cur` == dct), `acc` was free all
+        // along; otherwise its last reader was pass 0 of the inverse transform above, three barriers ago.
+        __syncthreads();
+        u32* rowidx = reinterpret_cast<u32*>(dct);                                      // digit rows + exchange buffers: all dead
+        u64* red = reinterpret_cast<u64*>(rowidx + ((N * P.dKS + 3) & ~3u));
+        u32* outp = P.pool + (size_t)(g.out + soff) * P.pool_stride;
+        const u64* coef = reinterpret_cast<const u64*>(acc);
+        if (P.ksk_u16) fused_tail<uint16_t, T>(P, coef, rowidx, red, outp, blockIdx.x, dbg_lweN, dbg_ks);
+        else fused_tail<u32, T>(P, coef, rowidx, red, outp, blockIdx.x, dbg_lweN, dbg_ks);
+    }
+}
+
+// LDS the fused tail needs inside the digit rows of the 16-wave N = 2048 kernel (T = 1024 threads)
+bool fused_tail64_fits(const DevParams& P) {
+    const size_t N = P.N, NP = N + (N >> 6) * 4, R = 2 * P.dG, T = 1024;
+    const size_t VW = P.ksk_u16 ? 8 : 4, G = (P.n + VW) / VW, Gv = G < T ? G : T, RW = (Gv + 63) / 64, SL = (T / 64) / RW;
+    const size_t need = ((N * P.dKS + 3) & ~(size_t)3) * 4 + SL * Gv * VW * 8;
+    return P.logN == 11 && (size_t)P.n + 1 <= T * VW && RW <= T / 64 && SL >= 1 && need <= R * NP * 8;
 }
 
 // key words u64 <-> double in place (exact: Q < 2^39)
@@ -1327,8 +1355,9 @@ size_t blind_rotate64_lds_bytes(const DevParams& P) {
 }
 
 hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
-                                 u64* acc_out, hipStream_t s) {
-    using K = void (*)(DevParams, const bce_gate_desc*, u32, u32, u64*);
+                                 u64* acc_out, hipStream_t s, u32* dbg_lweN, u32* dbg_ks, bool* tail_fused) {
+    using K = void (*)(DevParams, const bce_gate_desc*, u32, u32, u64*, u32*, u32*);
+    if (tail_fused) *tail_fused = false;
     const bool ap = P.method_ap != 0;
     u32 threads = 128 * P.dG;
     K kern = nullptr;
@@ -1341,7 +1370,10 @@ hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32
                 // items do not fit the 128-register budget (16 waves: +9 %).  BCE_VARIANT=2 / 3 force 8 / 16 waves.
                 const bool w16 = P.variant == 3 || (P.variant != 2 && ap);
                 if (w16) {
-                    if (P.fold) kern = ap ? wd::k_blind_rotate64d<11, 3, true, true, true, true> : wd::k_blind_rotate64d<11, 3, false, true, true, true>;
+                    // the AP build with the folded key (BASELINE config 5) carries the tail in its epilogue
+                    const bool fuse = ap && P.fold && tail_fused && P.fuse_tail && wd::fused_tail64_fits(P);
+                    if (fuse) { kern = wd::k_blind_rotate64d<11, 3, true, true, true, true, true>; *tail_fused = true; }
+                    else if (P.fold) kern = ap ? wd::k_blind_rotate64d<11, 3, true, true, true, true> : wd::k_blind_rotate64d<11, 3, false, true, true, true>;
                     else kern = ap ? wd::k_blind_rotate64d<11, 3, true, true, true> : wd::k_blind_rotate64d<11, 3, false, true, true>;
                     threads = 1024;
                 } else {
@@ -1369,7 +1401,9 @@ hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32
     const size_t lds = blind_rotate64_lds_bytes(P);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(n_desc * instances), dim3(threads), lds, s, P, d, n_desc, slot_stride, acc_out);
+    const bool fused = tail_fused && *tail_fused;
+    hipLaunchKernelGGL(kern, dim3(n_desc * instances), dim3(threads), lds, s, P, d, n_desc, slot_stride, acc_out,
+                       fused ? dbg_lweN : nullptr, fused ? dbg_ks : nullptr);
     return hipGetLastError();
 }
 
