@@ -1046,7 +1046,7 @@ int bce_dag_create(bce_ctx* c, uint32_t n_tasks, const bce_gate_desc* tasks, con
     if (!c || !out) return BCE_ERR_ARG;
     *out = nullptr;
     if (!tasks || n_tasks == 0) return c->fail(BCE_ERR_ARG, "bce_dag_create: empty task list");
-    if (!dag_kernel_available(c->P)) return c->fail(BCE_ERR_UNSUPPORTED, "bce_dag_create: no persistent kernel for this parameter class (N = 1024, 4 gadget digits, Q < 2^28 only)");
+    if (!dag_kernel_available(c->P)) return c->fail(BCE_ERR_UNSUPPORTED, "bce_dag_create: no persistent kernel for this parameter class (N = 1024, 4 gadget digits, Q < 2^28; N = 2048, Q < 2^39, AP with the folded key)");
     if ((u64)n_tasks >= (1ull << 31)) return c->fail(BCE_ERR_ARG, "bce_dag_create: too many tasks");
     HIP_TRY(c, hipSetDevice(c->device));
     u32 max_slot = 0;
@@ -1173,6 +1173,7 @@ int bce_dag_run(bce_ctx* c, bce_dag* g, uint32_t instances, uint32_t slot_stride
     int wps = c->dag_wg_per_cu == 1 ? 2 : 4;
     if (c->dag_wg_per_cu == 0) wps = (items / std::max<u32>(1, g->depth) <= (u64)c->P.cu_count * 3 / 4) ? 2 : 4;
     if (const char* e = std::getenv("BCE_DAG_WPS")) { if (e[0] == '2') wps = 2; else if (e[0] == '4') wps = 4; }
+    if (c->P.is64) wps = 2;      // the config-5 kernel: one 1,024-thread workgroup is all a CU's LDS holds
     if (const char* e = std::getenv("BCE_DAG_PLACE")) D.policy = e[0] == '0' ? 0u : 1u;
     const char* dbg = std::getenv("BCE_DAG_DEBUG");   // development: 'r' = re-arm only, 'd' = dry run (no bootstraps)
     if (dbg && dbg[0] == 'd') D.policy |= 2u;

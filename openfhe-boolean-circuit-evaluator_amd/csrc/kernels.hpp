@@ -117,6 +117,9 @@ hipError_t launch_dag_rearm(const DagParams& D, hipStream_t s);
 hipError_t launch_bootstrap_dag(const DevParams& P, const DevParams* d_P, const DagParams* d_params, int wps, u32 grid,
                                 hipStream_t s);
 bool dag_kernel_available(const DevParams& P);
+// the config-5 class (kernels64.hip): N = 2048, Q < 2^39 in doubles, AP, folded key, fused tail; 1,024 threads, one workgroup per CU
+bool dag64_kernel_available(const DevParams& P);
+hipError_t launch_bootstrap_dag64(const DevParams& P, const DevParams* d_P, const DagParams* d_params, u32 grid, hipStream_t s);
 
 // acc_out: u32 [n_boot][2][N], COEFFICIENT domain, values in [0, Q)
 // *kernel_id (optional) receives the enum bce_br_kernel value of the kernel that was launched

@@ -17,6 +17,7 @@
 
 namespace bce {
 #include "fused_tail.hpp"
+#include "dag_sched.hpp"
 #ifdef BCE_PHASE_PROF
 __device__ unsigned long long g_phase_prof64[BCE_PROF_WAVES * BCE_PROF_SLOTS];
 #define BCE_PROF_ARRAY ::bce::g_phase_prof64
@@ -992,18 +993,23 @@ __device__ __forceinline__ void split_inverse11(const double* src, double* bufA,
 // (33.6 MB for STD192) and write the refreshed ciphertext to the pool; no tail kernels, no accumulator round trip through HBM.
 template <int LOGN, int DG, bool AP, bool SPLIT = false, bool W16 = false, bool FOLD = false, bool FUSE = false,
           u32 NBUF_ = (W16 ? (AP ? BCE_W16_NBUF_AP : BCE_W16_NBUF_GINX) : (AP ? 3 : 2)),
-          u32 NPRE_ = (W16 ? (AP ? BCE_W16_NPRE_AP : BCE_W16_NPRE_GINX) : (AP ? 2 : 1))>
-__global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind_rotate64d(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
-                                                               u32 slot_stride, u64* __restrict__ acc_out,
-                                                               u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
+          u32 NPRE_ = (W16 ? (AP ? BCE_W16_NPRE_AP : BCE_W16_NPRE_GINX) : (AP ? 2 : 1)),
+          bool PERSIST = false, typename PT = DevParams>
+__device__ __forceinline__ void bootstrap64d(const PT& P, const bce_gate_desc g, const u32 soff, const u32 boot, double* smemd,
+                                             u64* __restrict__ acc_out, u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
+    // one gate bootstrap by one workgroup; `boot` = index of the bootstrap in the launch (acc_out / dbg rows).
+    // PERSIST (dataflow kernel, k_bootstrap_dag64): called from a loop -- the thread index is opaque per call so that the
+    // compiler cannot split the caller's loop on it, and nothing leaves through acc_out
     static_assert(!FUSE || (W16 && SPLIT), "fused tail: 16-wave build");
+    static_assert(!PERSIST || FUSE, "persistent callers rely on the fused tail");
     using C = Cfg<LOGN>;
     constexpr int N = C::N, NP = C::NP, E = C::E;
     constexpr u32 R = 2 * DG, T = W16 ? 1024 : (SPLIT ? 512 : 64 * R);
     static_assert(!SPLIT || (LOGN == 11 && R <= 8 && R >= 4), "split inverse transform: N = 2048");
     static_assert(!W16 || (SPLIT && R == 6), "16-wave variant: N = 2048, three gadget digits");
     static_assert(!FOLD || (SPLIT && R == 6), "folded gadget digit: N = 2048, three gadget digits");
-    extern __shared__ __align__(16) double smemd[];
+    u32 tid_o = threadIdx.x;
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid_o));
     double* acc = smemd;          // [2][NP] evaluation form, |value| <= 0.6 Q
     double* dct = acc + 2 * NP;   // [R][NP]
     u32* av = reinterpret_cast<u32*>(dct + R * NP);
@@ -1011,14 +1017,12 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
     // LDS mirror of the first 1024 twiddle entries (8-wave kernel only: 16 KiB of the 20 KiB left next to the polynomials)
     double2* twl = reinterpret_cast<double2*>(av + ((P.n + 1 + 3) & ~3u));
     if constexpr (SPLIT)
-        for (u32 i = threadIdx.x; i < 1024u; i += T) twl[i] = tw[i];
+        for (u32 i = tid_o; i < 1024u; i += T) twl[i] = tw[i];
     const Tw twa{tw, twl};
 
-    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 tid = tid_o, lane = tid & 63, wave = tid >> 6;
     const double Q = P.Qd, invQ = P.invQd;
     const u32 q = P.q, qm = q - 1, n = P.n;
-    const bce_gate_desc g = descs[blockIdx.x % n_desc];
-    const u32 soff = (blockIdx.x / n_desc) * slot_stride;
     {
         const u32* in0 = P.pool + (size_t)(g.in0 + soff) * P.pool_stride;
         const u32* in1 = P.pool + (size_t)(g.in1 + soff) * P.pool_stride;
@@ -1282,7 +1286,7 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
         const u32 c = wave >> 2, t = tid & 255u;
         double x[8];
         split_inverse11(cur + c * NP, dct + (XA + c) * NP, dct + (XB + c) * NP, twa, t, Q, x);
-        u64* out = acc_out + ((size_t)blockIdx.x * 2 + c) * N;
+        u64* out = acc_out + ((size_t)boot * 2 + c) * N;
         u64* coef = reinterpret_cast<u64*>(acc);   // FUSE: [2][N] u64 in the accumulator's own rows (dead: `cur` was read by pass 0)
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -1290,13 +1294,13 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
             const double v = y < 0.0 ? y + Q : y;
             const double hi = floor(v * (1.0 / 4294967296.0));
             const u64 wv = ((u64)(u32)hi << 32) | (u64)(u32)fma(-hi, 4294967296.0, v);
-            out[((u32)r << 8) | t] = wv;
+            if constexpr (!PERSIST) out[((u32)r << 8) | t] = wv;
             if constexpr (FUSE) coef[c * N + (((u32)r << 8) | t)] = wv;
         }
     } else if (wave < 2) {
         double x[E];
         ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, Tw{tw, nullptr}, lane, Q, ninv, x);
-        u64* out = acc_out + ((size_t)blockIdx.x * 2 + wave) * N;
+        u64* out = acc_out + ((size_t)boot * 2 + wave) * N;
 #pragma unroll
         for (int r = 0; r < E; ++r) {
             const double v = x[r] < 0.0 ? x[r] + Q : x[r];   // [0, Q), an integer below 2^39
@@ -1312,9 +1316,30 @@ __global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind
         u64* red = reinterpret_cast<u64*>(rowidx + ((N * P.dKS + 3) & ~3u));
         u32* outp = P.pool + (size_t)(g.out + soff) * P.pool_stride;
         const u64* coef = reinterpret_cast<const u64*>(acc);
-        if (P.ksk_u16) fused_tail<uint16_t, T>(P, coef, rowidx, red, outp, blockIdx.x, dbg_lweN, dbg_ks);
-        else fused_tail<u32, T>(P, coef, rowidx, red, outp, blockIdx.x, dbg_lweN, dbg_ks);
+        if (P.ksk_u16) fused_tail<uint16_t, T>(P, coef, rowidx, red, outp, boot, dbg_lweN, dbg_ks);
+        else fused_tail<u32, T>(P, coef, rowidx, red, outp, boot, dbg_lweN, dbg_ks);
     }
+}
+
+template <int LOGN, int DG, bool AP, bool SPLIT = false, bool W16 = false, bool FOLD = false, bool FUSE = false>
+__global__ __launch_bounds__(W16 ? 1024 : (SPLIT ? 512 : 128 * DG)) void k_blind_rotate64d(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
+                                                               u32 slot_stride, u64* __restrict__ acc_out,
+                                                               u32* __restrict__ dbg_lweN, u32* __restrict__ dbg_ks) {
+    extern __shared__ __align__(16) double smemd[];
+    bootstrap64d<LOGN, DG, AP, SPLIT, W16, FOLD, FUSE>(P, descs[blockIdx.x % n_desc], (blockIdx.x / n_desc) * slot_stride, blockIdx.x, smemd,
+                                                       acc_out, dbg_lweN, dbg_ks);
+}
+
+// Dataflow evaluation on the config-5 kernel (dag_sched.hpp): one persistent 1,024-thread workgroup per CU (the LDS holds
+// one), AP, folded key, fused tail.  No XCD start gate is needed for key locality here -- an AP step reads one RGSW
+// ciphertext chosen by the ciphertext's own digit, so workgroups share few key rows even in lock-step.
+__global__ __launch_bounds__(1024) void k_bootstrap_dag64(const DevParams* Pp, const DagParams* Dp) {
+    extern __shared__ __align__(16) double smemd[];
+    u32* mbox = reinterpret_cast<u32*>(smemd);
+    dag_worker(Dp, mbox, [&](ConstDagParams& D, u32 t, u32 k) {
+        bootstrap64d<11, 3, true, true, true, true, true, BCE_W16_NBUF_AP, BCE_W16_NPRE_AP, true>(
+            *as_constant<ConstDevParams>(Pp), D.tasks[t], D.slot_base + k * D.slot_stride, 0, smemd + kDagMailboxWords / 2, nullptr, nullptr, nullptr);
+    });
 }
 
 // LDS the fused tail needs inside the digit rows of the 16-wave N = 2048 kernel (T = 1024 threads)
@@ -1352,6 +1377,20 @@ size_t blind_rotate64_lds_bytes(const DevParams& P) {
     // the 8-wave double-precision kernel (N = 2048, 3 gadget digits) also mirrors the first 1024 twiddle entries
     const size_t mirror = (P.fp64 && P.logN == 11 && P.dG == 3) ? 1024 * sizeof(double2) : 0;
     return (2 + R) * NP * sizeof(u64) + ((P.n + 1 + 3) & ~3u) * sizeof(u32) + mirror;
+}
+
+bool dag64_kernel_available(const DevParams& P) {
+    // what launch_blind_rotate64 would run with the tail fused: AP, 16 waves, folded key
+    return P.is64 && P.fp64 && P.logN == 11 && P.dG == 3 && P.method_ap && P.fold && P.fuse_tail && P.variant != 2 && wd::fused_tail64_fits(P);
+}
+
+hipError_t launch_bootstrap_dag64(const DevParams& P, const DevParams* d_P, const DagParams* d_params, u32 grid, hipStream_t s) {
+    if (!dag64_kernel_available(P)) return hipErrorInvalidValue;
+    const size_t lds = blind_rotate64_lds_bytes(P) + kDagMailboxWords * 4;   // + the worker's mailbox in front
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wd::k_bootstrap_dag64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wd::k_bootstrap_dag64, dim3(grid), dim3(1024), lds, s, d_P, d_params);
+    return hipGetLastError();
 }
 
 hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,

@@ -123,3 +123,49 @@ def test_config5_aes_expanded_std192_ap_two_vectors(std192_ap, bce, orc):
         a, b = cc.lwe_read([slot(k, ins[0]), slot(k, ins[1])])
         got = cc.lwe_read([slot(k, out)])[0]
         assert np.array_equal(got, oracle_gate(op, a, b)), "config-5 circuit register of gate %s %s differs from the oracle" % (op, ins)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_config5_dataflow_kernel_leaves_the_step_schedule_s_registers(std192_ap, bce, tmp_path, seed):
+    """The dependency-driven schedule on the config-5 kernel (k_bootstrap_dag64: persistent 1,024-thread workgroups, AP,
+    folded key, fused tail): random Bristol Fashion netlists, K = 3, outputs against the Python evaluator, every register of
+    the K instances against the bootstrap-depth step schedule (whose kernel the stage test above pins on the oracle), and one
+    bootstrapped gate of the dataflow run replayed on the oracle from its input registers."""
+    import random
+    from test_random_circuits import random_netlist
+    o, cc = std192_ap
+    assert cc.dag_supported()
+    rnd = random.Random(5200 + seed)
+    text, in_w, out_w, evaluate = random_netlist(rnd, rnd.randint(30, 60))
+    path = tmp_path / "rand5.txt"
+    path.write_text(text)
+    K = 3
+    ins = [[[rnd.randint(0, 1) for _ in range(w)] for w in in_w] for _ in range(K)]
+    snap = {}
+    cc.set_encrypt_seed(SEED + 77 + seed)
+    for mode in ("steps", "dataflow"):
+        c = bce.Circuit(cc)
+        c.ReadBristol(str(path), new_flag=True)
+        c.setInstances(K)
+        c.Reset(); c.setEncrypted(True); c.setRelevel(True)
+        c.setDataflow(mode == "dataflow")
+        info = c.info()
+        W, stride = info["n_wires"], info["slot_stride"]
+        cc.pool_reserve(K * stride)
+        cc.lwe_write(np.arange(K * stride, dtype=np.uint32), np.zeros((K * stride, cc.n + 1), dtype=np.uint64))
+        for k in range(K):
+            c.SetInput(ins[k], instance=k)
+        t0 = cc.timing()
+        c.Clock()
+        t1 = cc.timing()
+        assert c.dataflowActive() == (mode == "dataflow")
+        if mode == "dataflow":
+            dag = [i for i, k in enumerate(t1["by_kernel"]) if "dag" in k["kernel"]]
+            assert len(dag) == 1 and t1["by_kernel"][dag[0]]["launches"] - t0["by_kernel"][dag[0]]["launches"] == 1
+            assert t1["blind_rotate_launches"] - t0["blind_rotate_launches"] == 1, "one persistent launch per evaluation"
+        for k in range(K):
+            assert c.Outputs(k) == evaluate(ins[k]), "instance %d, %s" % (k, mode)
+        snap[mode] = np.concatenate([cc.lwe_read(np.arange(k * stride, k * stride + W, dtype=np.uint32)) for k in range(K)])
+        c.close()
+    cc.set_encrypt_seed(None)
+    assert np.array_equal(snap["steps"], snap["dataflow"]), "config-5 dataflow registers differ from the step schedule"

@@ -155,7 +155,9 @@ def perf(cc, name, Ks, modes):
 
 
 def main():
-    cc = bce.BinFHEContext(bce.STD128_OPT, bce.GINX)
+    # DAG_PROBE_PARAMS=STD192:AP -> BASELINE config 5 (k_bootstrap_dag64)
+    ps, method = os.environ.get("DAG_PROBE_PARAMS", "STD128_OPT:GINX").split(":")
+    cc = bce.BinFHEContext(getattr(bce, ps), getattr(bce, method))
     cc.KeyGen(0x0FE5EED)
     if sys.argv[1] == "parity":
         parity(cc)
