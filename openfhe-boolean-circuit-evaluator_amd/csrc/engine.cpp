@@ -105,6 +105,8 @@ struct bce_ctx {
     void* d_acc = nullptr;
     size_t acc_cap = 0;  // bootstraps
     u64* d_tail_partial = nullptr;  // partial key-switch sums (kernels.hip, k_tail_gather)
+    u32 *d_io = nullptr, *h_io = nullptr;  // staging of bce_lwe_read for scattered slots (device gather + one pinned copy)
+    size_t io_cap = 0;
     size_t tail_cap = 0;            // u64 words
     static constexpr int kRing = 4;
     bce_gate_desc* d_descs[kRing] = {nullptr, nullptr, nullptr, nullptr};
@@ -660,6 +662,7 @@ void bce_ctx_destroy(bce_ctx* c) {
         if (c->h_descs[i]) hipHostFree(c->h_descs[i]);
         if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
     }
+    hipFree(c->d_io); if (c->h_io) hipHostFree(c->h_io);
     hipFree(c->d_P); if (c->h_dag_status) hipHostFree(c->h_dag_status); if (c->h_dag_stage) hipHostFree(c->h_dag_stage);
     hipFree(c->d_twf); hipFree(c->d_psi); hipFree(c->d_tw64); hipFree(c->d_tw64d); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc); hipFree(c->d_tail_partial);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -855,6 +858,8 @@ int bce_pool_reserve(bce_ctx* c, uint32_t slots) {
 
 uint32_t bce_pool_slots(const bce_ctx* c) { return c ? c->pool_slots : 0; }
 
+static int pool_pack(bce_ctx* c, const uint32_t* slots, uint32_t count, void* dev, int to_pool);
+
 int bce_lwe_write(bce_ctx* c, const uint32_t* slots, uint32_t count, const uint64_t* cts) {
     if (!c || !slots || !cts) return BCE_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -897,11 +902,21 @@ int bce_lwe_read(bce_ctx* c, const uint32_t* slots, uint32_t count, uint64_t* ct
         for (u32 i = 0; i < count; ++i)
             for (size_t k = 0; k < W; ++k) cts[i * W + k] = buf[(size_t)(slots[i] - lo) * W + k];
     } else {
-        buf.resize(W);
-        for (u32 i = 0; i < count; ++i) {
-            HIP_TRY(c, hipMemcpy(buf.data(), c->d_pool + (size_t)slots[i] * W, W * 4, hipMemcpyDeviceToHost));
-            for (size_t k = 0; k < W; ++k) cts[i * W + k] = buf[k];
+        // scattered slots (the outputs of K instances sit one pool stride apart): gather on the device, one copy
+        const size_t words = (size_t)count * W;
+        if (words > c->io_cap) {
+            if (c->d_io) hipFree(c->d_io);
+            if (c->h_io) hipHostFree(c->h_io);
+            c->d_io = nullptr; c->h_io = nullptr; c->io_cap = 0;
+            const size_t cap = std::max(words, (size_t)64 * W);
+            HIP_TRY(c, hipMalloc(&c->d_io, cap * sizeof(u32)));
+            HIP_TRY(c, hipHostMalloc(&c->h_io, cap * sizeof(u32)));
+            c->io_cap = cap;
         }
+        { const int rc = pool_pack(c, slots, count, c->d_io, 0); if (rc) return rc; }
+        HIP_TRY(c, hipMemcpyAsync(c->h_io, c->d_io, words * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (size_t k = 0; k < words; ++k) cts[k] = c->h_io[k];
     }
     return BCE_OK;
 }
@@ -968,9 +983,19 @@ int bce_decrypt_bits(bce_ctx* c, const uint32_t* slots, uint32_t count, uint8_t*
     if (rc) return rc;
     for (u32 i = 0; i < count; ++i) {
         const u64* ct = &cts[(size_t)i * W];
-        u128 inner = 0;
-        for (u32 k = 0; k < n; ++k) inner += (u128)ct[k] * lift_signed(c->s[k], q);
-        u64 r = (ct[n] + q - (u64)(inner % q)) % q;
+        // <a, s> over the integers with s in {-1, 0, 1}: |sum| < n q, reduced once (same residue as the reference's
+        // mod-q accumulation, lwe-pke.cpp Decrypt)
+        u64 inner_q;
+        if (q <= (1ull << 24)) {
+            int64_t inner = 0;
+            for (u32 k = 0; k < n; ++k) inner += (int64_t)ct[k] * c->s[k];
+            inner_q = (u64)(((inner % (int64_t)q) + (int64_t)q) % (int64_t)q);
+        } else {
+            u128 inner = 0;
+            for (u32 k = 0; k < n; ++k) inner += (u128)ct[k] * lift_signed(c->s[k], q);
+            inner_q = (u64)(inner % q);
+        }
+        u64 r = (ct[n] + q - inner_q) % q;
         r = (r + q / 8) % q;
         bits[i] = (uint8_t)((4 * r) / q);
     }
