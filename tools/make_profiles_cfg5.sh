@@ -13,8 +13,8 @@ cp "$SRC/quick_perf.log" "$P/${PRE}_cfg5_quick_perf.log"
 cd /tmp
 /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -S --cuda-device-only -o /tmp/bce_kernels64.s \
     "$R/openfhe-boolean-circuit-evaluator_amd/csrc/kernels64.hip" 2>/dev/null
-python3 "$R/tools/valu_model.py" /tmp/bce_kernels64.s k_blind_rotate64dILi11ELi3ELb1ELb1ELb1ELb1E "$P/${PRE}_valu_issue.jsonl" "$P/${PRE}_cfg5_pmc_sq.json" \
-    "wd::k_blind_rotate64d<11,3,AP,SPLIT,W16,FOLD> (STD192 / AP, 1,024 threads, folded key)" 4 > "$P/${PRE}_cfg5_valu_model.json"
+python3 "$R/tools/valu_model.py" /tmp/bce_kernels64.s k_blind_rotate64dILi11ELi3ELb1ELb1ELb1ELb1ELb1E "$P/${PRE}_valu_issue.jsonl" "$P/${PRE}_cfg5_pmc_sq.json" \
+    "wd::k_blind_rotate64d<11,3,AP,SPLIT,W16,FOLD,FUSE> (STD192 / AP, 1,024 threads, folded key, tail in the epilogue)" 4 > "$P/${PRE}_cfg5_valu_model.json"
 python3 - "$P" "$PRE" <<'PY'
 import csv, json, sys
 P, PRE = sys.argv[1:3]
