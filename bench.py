@@ -177,6 +177,8 @@ def main():
                     help="steps: one launch per dependent step of the bootstrap-depth schedule (default); dataflow: the whole "
                          "bootstrap DAG in one persistent launch with device-side ready queues (bce_dag_*)")
     ap.add_argument("--shard", choices=["instances", "gates"], default="instances")
+    ap.add_argument("--no-gates-weak", dest="gates_weak", action="store_false",
+                    help="skip the secondary gate-sharded run at K x N input blocks (N > 1)")
     ap.add_argument("--no-relevel", dest="relevel", action="store_false",
                     help="schedule by gate level exactly like the reference's Clock() rounds (496 launches for AES) instead of "
                          "by bootstrap depth (416 launches, identical ciphertexts)")
@@ -245,11 +247,12 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "circuits", args.circuit)
     K_total = args.instances
 
-    def run_mode(shard_mode, steps, warmup, relevel, exchange="callback"):
+    def run_mode(shard_mode, steps, warmup, relevel, exchange="callback", K_run=None):
         """One timed run.  shard_mode 0 (instances): every rank evaluates ITS OWN K input blocks with its own
         circuit object -- independent units, no data-path collective (only the barrier / reductions of this
         script).  shard_mode 1 (gates): ONE set of K blocks, every level's gates split over the ranks by bootstrap
         weight, boundary ciphertexts exchanged per level (RCCL allgather)."""
+        K_run = K_run or K_total
         circ = bce.Circuit(cc)
         circ.ReadBristol(path, new_flag=args.circuit.startswith("sha256_new"))
         if args.xor_fast:
@@ -262,7 +265,7 @@ def main():
         if args.schedule == "dataflow" and not gates:
             circ.setDataflow(True)
         info = circ.info()
-        circ.setInstances(K_total)
+        circ.setInstances(K_run)
         xch = None
         if gates:
             # boundary ciphertexts: the library's own RCCL all-gather on the engine stream when RCCL is the backend
@@ -273,7 +276,7 @@ def main():
         rng = np.random.default_rng(12345 + (0 if gates else rank))
         widths = info["n_input_bits"]
         inputs = []
-        for k in range(K_total):
+        for k in range(K_run):
             if args.circuit == "AES-expanded.txt" and k < 2:  # the reference's two vectors first
                 v = [x for x in kat.AES_VECTORS if x["circuit"] == "AES-expanded"][k]
                 inputs.append(kat.aes_case(v)[0])
@@ -282,21 +285,21 @@ def main():
         # plaintext pass = expected outputs (host logic only; under gate sharding it runs the same exchange plan on bits)
         circ.Reset()
         circ.setPlaintext(True)
-        for k in range(K_total):
+        for k in range(K_run):
             circ.SetInput(inputs[k], instance=k)
         circ.Clock()
-        expect = [circ.Outputs(k)[0] for k in range(K_total)]
+        expect = [circ.Outputs(k)[0] for k in range(K_run)]
         circ.Reset()
         circ.setEncrypted(True)
         if args.fresh_inputs:
             circ.setEncryptMode(bce.FRESH)
-        for k in range(K_total):
+        for k in range(K_run):
             circ.SetInput(inputs[k], instance=k)
         cc.synchronize()
         t_ready = time.time()
         df_active = circ.dataflowActive()
         xmod = importlib.import_module("openfhe-boolean-circuit-evaluator_amd.dist") if gates else None
-        k_ident = min(2, K_total)
+        k_ident = min(2, K_run)
         if gates:
             # ciphertext identity below compares the registers this rank holds after the run with a single-rank evaluation:
             # start from zeros, so that "holds" is readable from the pool (the pool may carry an earlier run's registers)
@@ -327,7 +330,7 @@ def main():
         elapsed = time.time() - t0
         tm = cc.timing()
         # correctness of the timed work: decrypted outputs of every instance == plaintext evaluation
-        verified = [circ.Outputs(k)[0] for k in range(K_total)] == expect
+        verified = [circ.Outputs(k)[0] for k in range(K_run)] == expect
         st = circ.stats()
         total_boot = float(tm["bootstraps"])
         if dist is not None:
@@ -558,6 +561,7 @@ def main():
             # the exit code says so (the parent prints "ranks failed"); no restart, no re-exec
             os._exit(3)
 
+    GW = GW_err = None
     wd = None
     if world > 1:
         wd = threading.Timer(args.gates_timeout, on_timeout)
@@ -578,7 +582,29 @@ def main():
                 G2 = run_mode(1, 1, 1, args.relevel, exchange="rccl")
             except Exception as e:
                 G2_err = repr(e)
+        # north_star's partition at the K that saturates every GPU: K x world input blocks in lock-step, every step's gates
+        # split over the ranks -- per-GPU work is what one GPU does alone with K blocks ("weak" scaling of the gate-sharded mode)
+        if G is not None and args.gates_weak:
+            try:
+                GW = run_mode(1, 1, 1, args.relevel, exchange=os.environ.get("BCE_EXCHANGE", "callback"), K_run=args.instances * world)
+            except Exception as e:
+                GW_err = repr(e)
     if rank == 0:
+        if GW is not None or GW_err is not None:
+            out["shard_gates_weak"] = ({"error": GW_err} if GW is None else {
+                "what": "%d x %d input blocks in lock-step, every step's gates split over the %d ranks by bootstrap weight, one allgather of the "
+                        "crossing outputs per step: the gate-sharded partition at the per-GPU load of the headline run" % (args.instances, world, world),
+                "value": GW["total_boot"] / GW["elapsed"], "unit": "gate-bootstraps/s", "scaling": "weak",
+                "instances_total": args.instances * world, "ms_per_step": GW["elapsed"] / GW["steps"] * 1e3, "steps": GW["steps"], "warmup": 1,
+                "exchanges_per_step": GW["exchanges_per_step"], "exchanged_cts_per_step": GW["exchanged_cts_per_step"],
+                "exchange_path": GW["exchange_path"], "outputs_verified": bool(GW["verified"]), "ciphertext_identity": GW["identity"]})
+            if GW is not None:
+                try:
+                    pred = importlib.import_module("openfhe-boolean-circuit-evaluator_amd.predict")
+                    if args.paramset in ("STD128_OPT", "STD128") and GW["relevel"]:
+                        out["shard_gates_weak"]["predicted"] = pred.predict_gate_sharding(path, args.circuit.startswith("sha256_new"), args.instances, weak=True)
+                except Exception as e:
+                    out["shard_gates_weak"]["predicted"] = {"error": repr(e)}
         if G_err is not None:
             out["shard_gates"] = {"error": G_err}
         if G is not None:

@@ -35,11 +35,15 @@ def launch_ms(n, lone=256, full=512):
 
 
 def predict_gate_sharding(circuit_path, new_flag, K, worlds=(1, 2, 4, 8), ct_bytes=2012, exch_us=60.0, link_GBps=150.0,
-                          locality=True):
+                          locality=True, weak=False):
+    """weak=False: K input blocks in all, whatever the world (strong scaling).  weak=True: K blocks PER GPU, i.e. K x world in
+    lock-step with every step's gates split over the ranks -- the per-GPU load of one GPU alone with K blocks."""
     bce = importlib.import_module(__package__)
     rows = []
     base = None
+    K_per = K
     for world in worlds:
+        K = K_per * world if weak else K_per
         plans, pubs = [], []
         for rank in range(world):
             c = bce.Circuit()
@@ -71,10 +75,15 @@ def predict_gate_sharding(circuit_path, new_flag, K, worlds=(1, 2, 4, 8), ct_byt
                "crossing_outputs_per_instance": crossing}
         if base is None:
             base = t
-        row["speedup_vs_1"] = round(base / t, 2)
-        row["efficiency"] = round(base / t / world, 3)
+        if weak:
+            row["instances"] = K
+            row["speedup_vs_1"] = round(base / t * world, 2)     # throughput ratio: world x the work in t instead of base
+            row["efficiency"] = round(base / t, 3)
+        else:
+            row["speedup_vs_1"] = round(base / t, 2)
+            row["efficiency"] = round(base / t / world, 3)
         rows.append(row)
-    return {"circuit": os.path.basename(circuit_path), "instances": K, "schedule": "bootstrap-depth, steps filled by slack for all ranks together",
+    return {"circuit": os.path.basename(circuit_path), "instances": ("%d per GPU" % K_per) if weak else K_per, "scaling": "weak" if weak else "strong", "schedule": "bootstrap-depth, steps filled by slack for all ranks together",
             "model": "max over ranks of the measured launch staircase per step + per-step all-gather (%.0f us + bytes over %.0f GB/s); "
                      "PREDICTION, not measured on more than one GPU" % (exch_us, link_GBps),
             "placement": "units follow their inputs' ranks" if locality else "contiguous in netlist order", "rows": rows}

@@ -52,6 +52,12 @@ def test_bench_gpus2_rehearsal_on_one_gpu():
     g = d["shard_gates"]
     assert g["outputs_verified"] is True and g["scaling"] == "strong"
     assert g["exchanges_per_step"] > 0 and g["exchanged_cts_per_step"] > 0
+    assert g["ciphertext_identity"]["identical_to_single_rank_evaluation"] is True
+    # the same partition at the headline's per-GPU load: K x N blocks in lock-step, gates split over the ranks
+    w = d["shard_gates_weak"]
+    assert w["scaling"] == "weak" and w["instances_total"] == 8 and w["outputs_verified"] is True
+    assert w["ciphertext_identity"]["identical_to_single_rank_evaluation"] is True
+    assert w["exchanged_cts_per_step"] > g["exchanged_cts_per_step"]
     assert "roofline" in d and "cpu_baseline" not in d               # the CPU baseline is an N = 1 leg
 
 

@@ -685,3 +685,29 @@ def test_other_parameter_sets_of_the_table_same_seed_keys(bce, orc, ps, fwd):
         assert o.decrypt(got[i]) == _truth(op, int(bits[2 * i]) ^ n0, int(bits[2 * i + 1]) ^ n1)
     o.close()
     c.close()
+
+
+def test_scattered_slots_read_and_decrypt_like_dense_ones(toy, bce):
+    """bce_lwe_read / bce_decrypt_bits on slots one pool stride apart (the outputs of K lock-step instances, what
+    Circuit::Clock decrypts) go through a device gather + one copy; dense requests through one plain copy.  Both must
+    return the words the oracle wrote, in request order (unsorted, with a repeated slot)."""
+    o, c = toy
+    rng = np.random.default_rng(77)
+    stride, K, W = 997, 40, 9
+    c.pool_reserve(stride * K + 16)
+    slots = np.array([k * stride + w for k in range(K) for w in range(W)], dtype=np.uint32)
+    bits = rng.integers(0, 2, len(slots)).astype(np.uint8)
+    cts = np.stack([o.encrypt(int(b), 5000 + i) for i, b in enumerate(bits)])
+    c.lwe_write(slots, cts)
+    order = rng.permutation(len(slots))
+    req = np.concatenate([slots[order], slots[order][:3]])            # scattered, unsorted, three repeats
+    got = c.lwe_read(req)
+    assert got.shape == (len(req), c.n + 1)
+    assert np.array_equal(got[:len(slots)], cts[order]) and np.array_equal(got[len(slots):], cts[order][:3])
+    assert list(c.Decrypt(req)) == list(bits[order]) + list(bits[order][:3])
+    # dense request over the same rows (one instance): same words
+    dense = np.arange(3 * stride, 3 * stride + W, dtype=np.uint32)
+    assert np.array_equal(c.lwe_read(dense), cts[3 * W:4 * W])
+    # a slot outside the pool is refused on both paths
+    with pytest.raises(bce.BceError):
+        c.lwe_read(np.array([0, stride * K + 10_000_000], dtype=np.uint32))
