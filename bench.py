@@ -173,9 +173,10 @@ def main():
     ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=None,
                     help="a BASELINE.json config by number: 2 adder_64bit (K = 256), 3 the headline (default), 4 sha256 (K = 16), "
                          "5 AES-expanded STD192 AP (K = 8); explicit --circuit / --paramset / --method / --instances win over it")
-    ap.add_argument("--schedule", choices=["steps", "dataflow"], default="steps",
+    ap.add_argument("--schedule", choices=["steps", "dataflow", "graph"], default="steps",
                     help="steps: one launch per dependent step of the bootstrap-depth schedule (default); dataflow: the whole "
-                         "bootstrap DAG in one persistent launch with device-side ready queues (bce_dag_*)")
+                         "bootstrap DAG in one persistent launch with device-side ready queues (bce_dag_*); graph: the step "
+                         "schedule's launches replayed as one hipGraph per evaluation (bce_plan_run; timed as one unit)")
     ap.add_argument("--shard", choices=["instances", "gates"], default="instances")
     ap.add_argument("--no-gates-weak", dest="gates_weak", action="store_false",
                     help="skip the secondary gate-sharded run at K x N input blocks (N > 1)")
@@ -264,6 +265,8 @@ def main():
             circ.setRelevel(True)
         if args.schedule == "dataflow" and not gates:
             circ.setDataflow(True)
+        if args.schedule == "graph" and not gates:
+            circ.setGraph(True)
         info = circ.info()
         circ.setInstances(K_run)
         xch = None
@@ -518,7 +521,8 @@ def main():
                 "baseline_config": args.config if args.config is not None else (3 if default_cmd else None),
                 "instances_per_gpu": args.instances, "sharding": args.shard,
                 "schedule": ("dataflow: the whole bootstrap DAG in one persistent launch, device-side ready queues (identical ciphertexts)" if R["dataflow"] else
-                             "bootstrap-depth levels (NOTs folded, steps filled by slack up to the launch staircase, identical ciphertexts)" if R["relevel"] else "gate levels (reference Clock rounds)"),
+                             ("bootstrap-depth levels (NOTs folded, steps filled by slack up to the launch staircase, identical ciphertexts)" +
+                              (", every evaluation's launches replayed as one hipGraph" if args.schedule == "graph" else "")) if R["relevel"] else "gate levels (reference Clock rounds)"),
                 "launches_per_step": R["launches_per_step"],
                 "reference_clock_rounds": info["n_levels"], "reference_sub_launches": info["n_sublaunches"],
                 "xor": "XOR_FAST (opt-in, 1 bootstrap)" if args.xor_fast else "NOT,NOT,AND,AND,OR (reference, 3 bootstraps)",

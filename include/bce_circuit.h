@@ -119,6 +119,12 @@ int bce_circuit_check_relevel(bce_circuit*);
  * sharding and for parameter classes without the persistent kernel: bce_circuit_dataflow_active tells. */
 int bce_circuit_set_dataflow(bce_circuit*, int on);
 int bce_circuit_dataflow_active(const bce_circuit*);   /* 1 if the next encrypted Clock() takes the dataflow path */
+/* Opt-in for the bootstrap-depth schedule (set_relevel): its launches are captured once into a hipGraph and every
+ * Clock() replays them with one launch (bce_plan_run) -- no per-step host call between the dependent kernels.  Same
+ * ciphertexts.  Without it the same resident descriptors are walked step by step (bce_plan_run_step).  Not with gate
+ * sharding (the per-step exchange is a host call), verify mode or the dataflow schedule: bce_circuit_graph_active tells. */
+int bce_circuit_set_graph(bce_circuit*, int on);
+int bce_circuit_graph_active(const bce_circuit*);
 /* The task list of the dataflow schedule (what bce_dag_create receives): gates in topological order with SSA slots for
  * ONE instance (slot < slot_stride of bce_circuit_get_info) and their priority classes.  Writes min(*n_tasks, cap)
  * entries to each non-NULL array and sets *n_tasks to the number of tasks (= bootstraps of one evaluation). */

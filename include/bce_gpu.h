@@ -70,7 +70,8 @@ enum bce_br_kernel {
     BCE_BR_SPLIT_X2 = 2,           /* k_blind_rotate_lat<4,4>: same, register budget for two workgroups per CU */
     BCE_BR_WORD64 = 3,             /* k_blind_rotate64: ring modulus >= 2^28 */
     BCE_BR_DAG = 4,                /* k_bootstrap_dag: one persistent launch per bce_dag_run (tail fused) */
-    BCE_BR_KERNELS = 5
+    BCE_BR_GRAPH = 5,              /* bce_plan_run: the launches of a whole step schedule replayed as one hipGraph (timed as one) */
+    BCE_BR_KERNELS = 6
 };
 
 /* cumulative device timing, measured with HIP events on the engine's stream */
@@ -174,6 +175,24 @@ int bce_eval_gates(bce_ctx*, uint32_t n_desc, const bce_gate_desc* descs);
 int bce_eval_gates_strided(bce_ctx*, uint32_t n_desc, const bce_gate_desc* descs, uint32_t instances,
                            uint32_t slot_stride);
 int bce_synchronize(bce_ctx*);
+
+/* ---- the hot path, a whole step schedule at once ----------------------------------------------------------
+ * A circuit's schedule is the same list of frontiers every time it is clocked (src/circuit.cpp:575-683 finds the same
+ * ready gates in the same order).  A bce_plan keeps the descriptors of ALL its dependent steps resident on the device:
+ *   bce_plan_run_step  = bce_eval_gates_strided for step `s` without the per-call descriptor upload (same kernels,
+ *                        same per-launch timing), the caller walks the steps (and may exchange ciphertexts between them);
+ *   bce_plan_run       = every step's launches captured once into a hipGraph and replayed with one hipGraphLaunch:
+ *                        no per-step host call, no upload, no event between dependent kernels.  Timed as one unit
+ *                        (BCE_BR_GRAPH).  Same ciphertexts in every register as the step-by-step form.
+ * Steps hold bootstrapped ops only (BCE_AND .. BCE_XNOR_FAST, BCE_OP_REFRESH); `descs` = the steps' descriptors back to
+ * back, step s has step_sizes[s] of them.  instances / slot_stride as in bce_eval_gates_strided; the slots are fixed at
+ * creation (slot_base shifts them all, e.g. a rank's first instance). */
+typedef struct bce_plan bce_plan;
+int bce_plan_create(bce_ctx*, uint32_t n_steps, const uint32_t* step_sizes, const bce_gate_desc* descs,
+                    uint32_t instances, uint32_t slot_stride, uint32_t slot_base, bce_plan** out);
+int bce_plan_run_step(bce_ctx*, bce_plan*, uint32_t step);
+int bce_plan_run(bce_ctx*, bce_plan*);
+void bce_plan_destroy(bce_ctx*, bce_plan*);
 
 /* ---- the hot path, dependency-driven ------------------------------------------------------------------
  * The reference alternates Circuit::_ManageGates (a gate is ready when every input wire has arrived,

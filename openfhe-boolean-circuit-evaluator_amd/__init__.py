@@ -43,7 +43,8 @@ class GateDesc(C.Structure):
 
 BR_KERNEL_NAMES = ["k_blind_rotate (one wave per transform)", "k_blind_rotate_lat<4,2> (split transform, 1 workgroup/CU)",
                    "k_blind_rotate_lat<4,4> (split transform, 2 workgroups/CU)", "k_blind_rotate64 (64-bit modulus)",
-                   "k_bootstrap_dag (persistent, dependency-driven, tail fused)"]
+                   "k_bootstrap_dag (persistent, dependency-driven, tail fused)",
+                   "captured step schedule (bce_plan_run: one hipGraph launch, timed as one)"]
 BR_KERNELS = len(BR_KERNEL_NAMES)
 
 
@@ -62,6 +63,7 @@ ENGINE_SYMBOLS = [
     "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_forward_transforms_per_step", "bce_launch_capacity", "bce_rccl_available", "bce_rccl_version", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
     "bce_rccl_shutdown", "bce_debug_eval_stages", "bce_debug_ntt",
     "bce_dag_supported", "bce_dag_create", "bce_dag_run", "bce_dag_destroy", "bce_dag_set_limits", "bce_dag_last_run", "bce_dag_debug_block_task",
+    "bce_plan_create", "bce_plan_run_step", "bce_plan_run", "bce_plan_destroy",
 ]
 
 _lib = None
@@ -135,6 +137,11 @@ def lib():
     L.bce_dag_set_limits.argtypes = [vp, i32, i32, u32, u32]
     L.bce_dag_last_run.argtypes = [vp, C.POINTER(u64)]
     L.bce_dag_debug_block_task.argtypes = [vp, u32]
+    L.bce_plan_create.argtypes = [vp, u32, vp, vp, u32, u32, u32, C.POINTER(vp)]
+    L.bce_plan_run_step.argtypes = [vp, vp, u32]
+    L.bce_plan_run.argtypes = [vp, vp]
+    L.bce_plan_destroy.argtypes = [vp, vp]
+    L.bce_plan_destroy.restype = None
     _lib = L
     return L
 
@@ -344,6 +351,28 @@ class BinFHEContext:
             d["gate_ms_per_bootstrap"] = round(out[6] / out[0] / 1e5, 4)
         return d
 
+    # --- a whole step schedule resident on the device (bce_plan_*) ---
+    def plan_create(self, steps, instances=1, slot_stride=0, slot_base=0):
+        """steps: list of frontiers, each a list of (op, in0, in1, out[, neg0, neg1]); returns an opaque handle"""
+        flat = [t for st in steps for t in st]
+        arr = (GateDesc * max(1, len(flat)))()
+        for i, t in enumerate(flat):
+            arr[i] = GateDesc(*(tuple(t) + (0, 0))[:6])
+        sizes = (C.c_uint32 * max(1, len(steps)))(*[len(st) for st in steps])
+        h = C.c_void_p()
+        self._ck(self._L.bce_plan_create(self.h, len(steps), sizes, arr, int(instances), int(slot_stride), int(slot_base), C.byref(h)))
+        return h
+
+    def plan_run_step(self, plan, step):
+        self._ck(self._L.bce_plan_run_step(self.h, plan, int(step)))
+
+    def plan_run(self, plan):
+        """every step's launches as ONE hipGraph launch (captured at the first call)"""
+        self._ck(self._L.bce_plan_run(self.h, plan))
+
+    def plan_destroy(self, plan):
+        self._L.bce_plan_destroy(self.h, plan)
+
     def dag_debug_block_task(self, dag, t):
         self._ck(self._L.bce_dag_debug_block_task(dag, int(t)))
 
@@ -433,7 +462,7 @@ CIRCUIT_SYMBOLS = [
     "bce_circuit_create", "bce_circuit_destroy", "bce_circuit_last_error", "bce_circuit_read_file",
     "bce_circuit_read_bristol", "bce_circuit_get_info", "bce_circuit_reset", "bce_circuit_rearm", "bce_circuit_set_plaintext",
     "bce_circuit_set_encrypted", "bce_circuit_set_verify", "bce_circuit_get_flags", "bce_circuit_set_batched",
-    "bce_circuit_set_encrypt_mode", "bce_circuit_get_encrypt_mode", "bce_circuit_plan_hash", "bce_circuit_set_shard_locality", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_dataflow", "bce_circuit_dataflow_active", "bce_circuit_dataflow_plan", "bce_circuit_set_balance", "bce_circuit_relevel_steps", "bce_circuit_relevel_publications", "bce_circuit_check_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
+    "bce_circuit_set_encrypt_mode", "bce_circuit_get_encrypt_mode", "bce_circuit_plan_hash", "bce_circuit_set_shard_locality", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_dataflow", "bce_circuit_dataflow_active", "bce_circuit_set_graph", "bce_circuit_graph_active", "bce_circuit_dataflow_plan", "bce_circuit_set_balance", "bce_circuit_relevel_steps", "bce_circuit_relevel_publications", "bce_circuit_check_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
     "bce_circuit_get_output", "bce_circuit_get_buses", "bce_circuit_get_counts", "bce_circuit_get_stats", "bce_circuit_dump",
     "bce_circuit_set_exchange", "bce_circuit_enable_rccl", "bce_circuit_exchange_capacity", "bce_assemble_bristol", "bce_pool_gather",
     "bce_pool_scatter",
@@ -464,6 +493,8 @@ def _bind_circuit():
     L.bce_circuit_set_instances.argtypes = [vp, u32]
     L.bce_circuit_set_balance.argtypes = [vp, i32, u32, u32]
     L.bce_circuit_set_dataflow.argtypes = [vp, i32]
+    L.bce_circuit_set_graph.argtypes = [vp, i32]
+    L.bce_circuit_graph_active.argtypes = [vp]
     L.bce_circuit_get_encrypt_mode.argtypes = [vp]
     L.bce_circuit_set_shard_locality.argtypes = [vp, i32]
     L.bce_circuit_plan_hash.argtypes = [vp]
@@ -636,6 +667,13 @@ class Circuit:
         pr = (C.c_uint8 * max(1, n.value))()
         self._ck(self._L.bce_circuit_dataflow_plan(self.h, arr, pr, n.value, C.byref(n)))
         return ([(a.op, a.in0, a.in1, a.out, a.neg0, a.neg1) for a in arr[:n.value]], [int(x) for x in pr[:n.value]])
+
+    def setGraph(self, b):
+        """replay the bootstrap-depth schedule as one hipGraph per Clock() (bce_plan_run); opt-in, same ciphertexts"""
+        self._ck(self._L.bce_circuit_set_graph(self.h, int(b)))
+
+    def graphActive(self):
+        return bool(self._L.bce_circuit_graph_active(self.h))
 
     def dataflowActive(self):
         return bool(self._L.bce_circuit_dataflow_active(self.h))

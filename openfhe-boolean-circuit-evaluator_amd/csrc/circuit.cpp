@@ -175,6 +175,7 @@ Circuit::Circuit(bce_ctx* engine) : cc(engine) {
 
 Circuit::~Circuit() {
     dropDag();
+    dropPlan();
     if (owns_engine_ && cc) bce_ctx_destroy(cc);
 }
 
@@ -722,7 +723,16 @@ void Circuit::unitSuccessorsAlap(const std::vector<Unit>& units, uint32_t D, std
     }
 }
 
+void Circuit::dropPlan() {
+    if (plan_) { bce_plan_destroy(cc, plan_); plan_ = nullptr; }
+}
+
+bool Circuit::graphActive() const {
+    return graph_ && cc && relevel_ && !dataflowActive() && !verify_flag && !(world_ > 1 && shard_mode_ == 1);
+}
+
 void Circuit::buildRelevelPlan() {
+    dropPlan();   // the resident copy of the schedule belongs to the plan it was built from
     const size_t W = wire_names_.size();
     std::vector<int> base;
     std::vector<uint8_t> neg;
@@ -1012,17 +1022,32 @@ void Circuit::clockReleveled() {
     const uint32_t K = hi - lo;
     if (relevel_plan_.empty() || (balance_ && relevel_K_ != std::max(1u, K))) rebuildRelevel();
     if (relevel_stride_ > stride_) throw std::logic_error("re-levelled schedule needs more scratch slots than the pool stride");
-    auto launch = [&](const std::vector<bce_gate_desc>& src) {
-        if (src.empty()) return;
-        std::vector<bce_gate_desc> d(src);
-        for (auto& e : d) { e.in0 += lo * stride_; e.in1 += lo * stride_; e.out += lo * stride_; }
-        ck(bce_eval_gates_strided(cc, (uint32_t)d.size(), d.data(), K, stride_), "Clock(re-levelled step)");
-        ++stats_.sublaunches;
-    };
     const bool sharded = world_ > 1 && shard_mode_ == 1;
-    for (size_t s = 0; s < relevel_plan_.size(); ++s) {
-        launch(relevel_plan_[s].descs);
-        if (sharded) exchangeWires(relevel_xw_[s]);   // outputs of this step whose consumers sit on other ranks
+    // the schedule's descriptors live on the device from the first Clock() on (bce_plan): a step is one call without an
+    // upload; with setGraph the whole schedule is one hipGraph launch
+    if (plan_ && (plan_lo_ != lo || plan_K_ != K || plan_stride_ != stride_)) dropPlan();
+    if (!plan_ && K) {
+        std::vector<uint32_t> sizes;
+        std::vector<bce_gate_desc> all;
+        for (const auto& st : relevel_plan_)
+            if (!st.descs.empty()) { sizes.push_back((uint32_t)st.descs.size()); all.insert(all.end(), st.descs.begin(), st.descs.end()); }
+        if (!sizes.empty()) {
+            ck(bce_plan_create(cc, (uint32_t)sizes.size(), sizes.data(), all.data(), K, stride_, lo * stride_, &plan_), "Clock(schedule upload)");
+            plan_lo_ = lo; plan_K_ = K; plan_stride_ = stride_;
+        }
+    }
+    if (plan_ && graphActive()) {
+        ck(bce_plan_run(cc, plan_), "Clock(schedule graph)");
+        for (const auto& st : relevel_plan_) if (!st.descs.empty()) ++stats_.sublaunches;
+    } else {
+        uint32_t ps = 0;
+        for (size_t s = 0; s < relevel_plan_.size(); ++s) {
+            if (plan_ && !relevel_plan_[s].descs.empty()) {
+                ck(bce_plan_run_step(cc, plan_, ps++), "Clock(re-levelled step)");
+                ++stats_.sublaunches;
+            }
+            if (sharded) exchangeWires(relevel_xw_[s]);   // outputs of this step whose consumers sit on other ranks
+        }
     }
     finishReleveled(lo, hi);
     stats_.levels = (uint32_t)relevel_plan_.size();

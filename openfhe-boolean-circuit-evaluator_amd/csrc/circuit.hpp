@@ -140,6 +140,11 @@ public:
     // without the persistent kernel.
     void setDataflow(bool b);
     bool getDataflow() const { return dataflow_; }
+    // opt-in: replay the bootstrap-depth schedule's launches as ONE hipGraph per Clock() (bce_plan_run) instead of one
+    // host call per step.  Same ciphertexts.  Not with gate sharding (the per-step exchange is a host call) or verify mode.
+    void setGraph(bool b) { graph_ = b; }
+    bool getGraph() const { return graph_; }
+    bool graphActive() const;
     bool dataflowActive() const;
     const std::vector<bce_gate_desc>& dataflowTasks() const { return dag_tasks_; }
     const std::vector<uint8_t>& dataflowPriorities() const { return dag_prio_; }
@@ -249,6 +254,10 @@ private:
                                    std::vector<uint32_t>& alap);
     bool dataflow_ = false;
     bce_dag* dag_ = nullptr;
+    bool graph_ = false;
+    bce_plan* plan_ = nullptr;                 // the schedule's descriptors resident on the device (and its captured graph)
+    uint32_t plan_lo_ = 0, plan_K_ = 0, plan_stride_ = 0;
+    void dropPlan();
     std::vector<bce_gate_desc> dag_tasks_;
     std::vector<uint8_t> dag_prio_;
     uint32_t dag_stride_ = 0;

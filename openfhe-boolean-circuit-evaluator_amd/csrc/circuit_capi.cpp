@@ -88,6 +88,8 @@ uint64_t bce_circuit_plan_hash(const bce_circuit* h) { return h ? h->c.planHash(
 int bce_circuit_get_encrypt_mode(const bce_circuit* h) { return h ? h->c.getEncryptMode() : -1; }
 int bce_circuit_set_dataflow(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setDataflow(on != 0); }); }
 int bce_circuit_dataflow_active(const bce_circuit* h) { return h && h->c.dataflowActive() ? 1 : 0; }
+int bce_circuit_set_graph(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setGraph(on != 0); }); }
+int bce_circuit_graph_active(const bce_circuit* h) { return h && h->c.graphActive() ? 1 : 0; }
 int bce_circuit_dataflow_plan(const bce_circuit* h, bce_gate_desc* tasks, uint8_t* prio, uint32_t cap, uint32_t* n_tasks) {
     if (!h || !n_tasks) return BCE_ERR_ARG;
     const auto& t = h->c.dataflowTasks();

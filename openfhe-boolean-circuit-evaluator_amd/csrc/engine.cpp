@@ -536,6 +536,55 @@ int sync_stream(bce_ctx* c) {
     return check_dag_runs(c);
 }
 
+// One frontier of bootstrapped gates whose descriptors already sit on the device: blind rotation (+ the tail kernels
+// when the blind-rotation kernel does not carry it).  timed: HIP events around each kernel group + the counters of
+// bce_timing; untimed (stream capture of bce_plan_run): launches only, *fused_out says whether the tail was fused.
+int launch_bootstraps(bce_ctx* c, const bce_gate_desc* dd, u32 n, u32 instances, u32 slot_stride, void* d_acc,
+                      u32* d_lweN, u32* d_ks, bool timed, bool* fused_out, u64* d_partial = nullptr) {
+    const size_t nb = (size_t)n * instances;
+    int kid = BCE_BR_WORD64;
+    bool tail_fused = false;
+    EventPair e0{};
+    if (timed) { e0 = get_events(c, 0); hipEventRecord(e0.a, c->stream); }
+    if (c->is64) HIP_TRY(c, launch_blind_rotate64(c->P, dd, n, instances, slot_stride, static_cast<u64*>(d_acc), c->stream, d_lweN, d_ks, &tail_fused));
+    else HIP_TRY(c, launch_blind_rotate(c->P, dd, n, instances, slot_stride, static_cast<u32*>(d_acc), c->stream, &kid, d_lweN, d_ks, &tail_fused));
+    if (timed) {
+        hipEventRecord(e0.b, c->stream);
+        e0.kind = kid;
+        c->pending.push_back(e0);
+        c->timing.br_launches[kid] += 1;
+        c->timing.br_bootstraps[kid] += nb;
+    }
+    if (!tail_fused) {
+        EventPair e1{};
+        if (timed) {
+            e1 = get_events(c, BCE_BR_KERNELS);  // kind >= BCE_BR_KERNELS: tail
+            hipEventRecord(e1.a, c->stream);
+        }
+        if (!d_partial) {
+            const size_t need = tail_partial_words(c->P, (u32)nb);
+            if (need > c->tail_cap) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if (c->d_tail_partial) hipFree(c->d_tail_partial);
+                c->d_tail_partial = nullptr;
+                const size_t cap = std::max(need, c->tail_cap * 2);
+                HIP_TRY(c, hipMalloc(&c->d_tail_partial, cap * sizeof(u64)));
+                c->tail_cap = cap;
+            }
+        }
+        HIP_TRY(c, launch_tail(c->P, dd, n, instances, slot_stride, d_acc, d_partial ? d_partial : c->d_tail_partial, d_lweN, d_ks, c->stream));
+        if (timed) { hipEventRecord(e1.b, c->stream); c->pending.push_back(e1); }
+    } else if (timed) {
+        c->timing.fused_tail_launches += 1;
+    }
+    if (timed) {
+        c->timing.blind_rotate_launches += 1;
+        c->timing.bootstraps += nb;
+    }
+    if (fused_out) *fused_out = tail_fused;
+    return BCE_OK;
+}
+
 int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances, u32 slot_stride, u64* dbg_acc,
               u64* dbg_lweN, u64* dbg_ks) {
     if (n_desc == 0 || instances == 0) return BCE_OK;
@@ -566,41 +615,10 @@ int eval_impl(bce_ctx* c, u32 n_desc, const bce_gate_desc* descs, u32 instances,
         u32 *d_lweN = nullptr, *d_ks = nullptr;
         if (dbg_lweN) HIP_TRY(c, hipMalloc(&d_lweN, nb * (c->N + 1) * sizeof(u32)));
         if (dbg_ks) HIP_TRY(c, hipMalloc(&d_ks, nb * (c->n + 1) * sizeof(u32)));
-        EventPair e0 = get_events(c, 0);
-        int kid = BCE_BR_WORD64;
-        bool tail_fused = false;
-        hipEventRecord(e0.a, c->stream);
-        if (c->is64) HIP_TRY(c, launch_blind_rotate64(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u64*>(c->d_acc), c->stream, d_lweN, d_ks, &tail_fused));
-        else HIP_TRY(c, launch_blind_rotate(c->P, dd, (u32)boot.size(), instances, slot_stride, static_cast<u32*>(c->d_acc), c->stream, &kid, d_lweN, d_ks, &tail_fused));
-        hipEventRecord(e0.b, c->stream);
-        e0.kind = kid;
-        c->pending.push_back(e0);
-        c->timing.br_launches[kid] += 1;
-        c->timing.br_bootstraps[kid] += nb;
-        if (!tail_fused) {
-            EventPair e1 = get_events(c, BCE_BR_KERNELS);  // kind >= BCE_BR_KERNELS: tail
-            hipEventRecord(e1.a, c->stream);
-            {
-                const size_t need = tail_partial_words(c->P, (u32)nb);
-                if (need > c->tail_cap) {
-                    HIP_TRY(c, hipStreamSynchronize(c->stream));
-                    if (c->d_tail_partial) hipFree(c->d_tail_partial);
-                    c->d_tail_partial = nullptr;
-                    const size_t cap = std::max(need, c->tail_cap * 2);
-                    HIP_TRY(c, hipMalloc(&c->d_tail_partial, cap * sizeof(u64)));
-                    c->tail_cap = cap;
-                }
-            }
-            HIP_TRY(c, launch_tail(c->P, dd, (u32)boot.size(), instances, slot_stride, c->d_acc, c->d_tail_partial, d_lweN, d_ks, c->stream));
-            hipEventRecord(e1.b, c->stream);
-            c->pending.push_back(e1);
-        } else {
-            c->timing.fused_tail_launches += 1;
-        }
+        rc = launch_bootstraps(c, dd, (u32)boot.size(), instances, slot_stride, c->d_acc, d_lweN, d_ks, true, nullptr);
+        if (rc) return rc;
         hipEventRecord(c->ring_ev[slot], c->stream);
         c->ring_busy[slot] = true;
-        c->timing.blind_rotate_launches += 1;
-        c->timing.bootstraps += nb;
         if (dbg_acc || dbg_lweN || dbg_ks) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             std::vector<u32> tmp;
@@ -1017,6 +1035,151 @@ int bce_synchronize(bce_ctx* c) {
     if (!c) return BCE_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     return sync_stream(c);
+}
+
+// ---- a whole step schedule at once (include/bce_gpu.h, "a whole step schedule at once") ---------------------------
+}  // extern "C" (the object below is C++)
+
+struct bce_plan {
+    std::vector<u32> off, cnt;                 // step s = descriptors [off[s], off[s] + cnt[s])
+    u32 instances = 0, slot_stride = 0;
+    u32 max_step = 0;                          // descriptors of the largest step
+    u64 boots_per_run = 0;
+    bce_gate_desc* d_descs = nullptr;          // all steps, resident
+    // captured form (bce_plan_run): its own accumulator / partial-sum scratch, so that nothing the graph points to is ever
+    // re-allocated by other calls on the context
+    void* d_acc = nullptr;
+    u64* d_partial = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    u64 fused_launches = 0;
+    // the captured kernels hold the context's device pointers and kernel choices by value: what they were at capture
+    const void* cap_ptrs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    u32 cap_flags[3] = {0, 0, 0};
+};
+
+namespace {
+bool plan_capture_is_current(const bce_ctx* c, const bce_plan* p) {
+    const void* now[6] = {c->P.pool, c->P.bsk, c->P.bsk64, c->P.ksk, c->P.tw_f, c->P.psi_tab};
+    const u32 flags[3] = {c->P.variant, c->P.fuse_tail, c->P.fold};
+    return std::memcmp(now, p->cap_ptrs, sizeof now) == 0 && std::memcmp(flags, p->cap_flags, sizeof flags) == 0;
+}
+}  // namespace
+
+extern "C" {
+
+void bce_plan_destroy(bce_ctx* c, bce_plan* p) {
+    if (!p) return;
+    if (c) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); }
+    if (p->exec) hipGraphExecDestroy(p->exec);
+    if (p->graph) hipGraphDestroy(p->graph);
+    hipFree(p->d_descs); hipFree(p->d_acc); hipFree(p->d_partial);
+    delete p;
+}
+
+int bce_plan_create(bce_ctx* c, uint32_t n_steps, const uint32_t* step_sizes, const bce_gate_desc* descs, uint32_t instances,
+                    uint32_t slot_stride, uint32_t slot_base, bce_plan** out) {
+    if (!c || !out) return BCE_ERR_ARG;
+    *out = nullptr;
+    if (!step_sizes || !descs || n_steps == 0 || instances == 0) return c->fail(BCE_ERR_ARG, "bce_plan_create: empty schedule");
+    if (!c->have_keys) return c->fail(BCE_ERR_NO_KEYS, "bce_keygen / bce_import_keys has not been called");
+    HIP_TRY(c, hipSetDevice(c->device));
+    struct Deleter { bce_ctx* c; void operator()(bce_plan* p) const { bce_plan_destroy(c, p); } };
+    std::unique_ptr<bce_plan, Deleter> p(new bce_plan, Deleter{c});
+    p->instances = instances; p->slot_stride = slot_stride;
+    u64 total = 0;
+    for (u32 s = 0; s < n_steps; ++s) {
+        if (step_sizes[s] == 0) return c->fail(BCE_ERR_ARG, "bce_plan_create: step %u is empty", s);
+        p->off.push_back((u32)total); p->cnt.push_back(step_sizes[s]);
+        p->max_step = std::max(p->max_step, step_sizes[s]);
+        total += step_sizes[s];
+        if (total >= (1ull << 31)) return c->fail(BCE_ERR_ARG, "bce_plan_create: too many descriptors");
+    }
+    std::vector<bce_gate_desc> d(descs, descs + total);
+    const u64 span = (u64)slot_base + (u64)(instances - 1) * slot_stride;
+    for (u64 i = 0; i < total; ++i) {
+        bce_gate_desc& g = d[i];
+        const bool two = g.op <= BCE_XNOR_FAST;
+        if (!two && g.op != BCE_OP_REFRESH) return c->fail(BCE_ERR_ARG, "bce_plan_create: descriptor %llu is not a bootstrapped gate (op %u)", (unsigned long long)i, g.op);
+        u64 hi = std::max<u64>(g.in0, g.out);
+        if (two) hi = std::max<u64>(hi, g.in1);
+        if (hi + span >= c->pool_slots) return c->fail(BCE_ERR_POOL, "bce_plan_create: descriptor %llu: slot %llu outside the pool (%u slots)", (unsigned long long)i, (unsigned long long)(hi + span), c->pool_slots);
+        g.in0 += slot_base; g.in1 += slot_base; g.out += slot_base;
+    }
+    p->boots_per_run = total * instances;
+    HIP_TRY(c, hipMalloc(&p->d_descs, total * sizeof(bce_gate_desc)));
+    HIP_TRY(c, hipMemcpy(p->d_descs, d.data(), total * sizeof(bce_gate_desc), hipMemcpyHostToDevice));
+    *out = p.release();
+    return BCE_OK;
+}
+
+int bce_plan_run_step(bce_ctx* c, bce_plan* p, uint32_t step) {
+    if (!c || !p) return BCE_ERR_ARG;
+    if (step >= p->cnt.size()) return c->fail(BCE_ERR_ARG, "bce_plan_run_step: step %u of %zu", step, p->cnt.size());
+    if (!c->have_keys) return c->fail(BCE_ERR_NO_KEYS, "bce_keygen / bce_import_keys has not been called");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int rc = ensure_acc(c, (size_t)p->cnt[step] * p->instances);
+    if (rc) return rc;
+    const int rc2 = launch_bootstraps(c, p->d_descs + p->off[step], p->cnt[step], p->instances, p->slot_stride, c->d_acc, nullptr, nullptr, true, nullptr);
+    if (rc2) return rc2;
+    if (c->pending.size() > 4096) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        drain_timing(c);
+    }
+    return BCE_OK;
+}
+
+int bce_plan_run(bce_ctx* c, bce_plan* p) {
+    if (!c || !p) return BCE_ERR_ARG;
+    if (!c->have_keys) return c->fail(BCE_ERR_NO_KEYS, "bce_keygen / bce_import_keys has not been called");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (p->exec && !plan_capture_is_current(c, p)) {
+        // the pool grew (bce_pool_reserve) or keys were re-imported since the capture: the graph's kernel arguments are stale
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipGraphExecDestroy(p->exec); p->exec = nullptr;
+        hipGraphDestroy(p->graph); p->graph = nullptr;
+    }
+    if (!p->exec) {
+        // scratch of the captured launches, sized for the largest step
+        const size_t nb = (size_t)p->max_step * p->instances;
+        if (!p->d_acc) HIP_TRY(c, hipMalloc(&p->d_acc, nb * 2 * c->N * c->wbytes));
+        if (!p->d_partial) HIP_TRY(c, hipMalloc(&p->d_partial, std::max<size_t>(1, tail_partial_words(c->P, (u32)nb)) * sizeof(u64)));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        // relaxed mode: the launchers set kernel attributes (dynamic LDS size) while the stream is capturing
+        HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+        int rc = BCE_OK;
+        u64 fused = 0;
+        for (size_t s = 0; s < p->cnt.size() && rc == BCE_OK; ++s) {
+            bool f = false;
+            rc = launch_bootstraps(c, p->d_descs + p->off[s], p->cnt[s], p->instances, p->slot_stride, p->d_acc, nullptr, nullptr, false, &f, p->d_partial);
+            fused += f ? 1 : 0;
+        }
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(c->stream, &g);   // always end the capture, also after a failed launch
+        if (rc != BCE_OK) { if (g) hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess || !g) return c->fail(BCE_ERR_HIP, "bce_plan_run: stream capture failed: %s", hipGetErrorString(e));
+        p->graph = g;
+        p->fused_launches = fused;
+        { const void* now[6] = {c->P.pool, c->P.bsk, c->P.bsk64, c->P.ksk, c->P.tw_f, c->P.psi_tab}; std::memcpy(p->cap_ptrs, now, sizeof now); }
+        p->cap_flags[0] = c->P.variant; p->cap_flags[1] = c->P.fuse_tail; p->cap_flags[2] = c->P.fold;
+        const hipError_t e2 = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+        if (e2 != hipSuccess) { p->exec = nullptr; return c->fail(BCE_ERR_HIP, "bce_plan_run: hipGraphInstantiate: %s", hipGetErrorString(e2)); }
+    }
+    EventPair e0 = get_events(c, BCE_BR_GRAPH);
+    hipEventRecord(e0.a, c->stream);
+    HIP_TRY(c, hipGraphLaunch(p->exec, c->stream));
+    hipEventRecord(e0.b, c->stream);
+    c->pending.push_back(e0);
+    c->timing.br_launches[BCE_BR_GRAPH] += p->cnt.size();
+    c->timing.br_bootstraps[BCE_BR_GRAPH] += p->boots_per_run;
+    c->timing.blind_rotate_launches += p->cnt.size();
+    c->timing.bootstraps += p->boots_per_run;
+    c->timing.fused_tail_launches += p->fused_launches;
+    if (c->pending.size() > 4096) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        drain_timing(c);
+    }
+    return BCE_OK;
 }
 
 // ---- dependency-driven evaluation (include/bce_gpu.h, "the hot path, dependency-driven") --------------------------

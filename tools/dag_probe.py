@@ -137,6 +137,8 @@ def perf(cc, name, Ks, modes):
             c.Reset(); c.setEncrypted(True); c.setRelevel(True)
             if mode.startswith("dataflow"):
                 c.setDataflow(True)
+            if mode.startswith("graph"):
+                c.setGraph(True)
             for k in range(K):
                 c.SetInput(ins[k], instance=k)
             c.Clock()
