@@ -1165,6 +1165,8 @@ __device__ __forceinline__ void lat_bootstrap(const PT& P, const bce_gate_desc g
         // (folded key: the half-row waves 4..7 -- the younger ones, which the arbiter serves last -- one level above the
         // whole-row waves, so that both kinds finish the phase together: -2 % per saturated launch, profiles/r02_prio_ab.log)
         if constexpr (WPS >= 4) { if (FOLD && wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#ifndef BCE_SKIP_FWD   // development: -DBCE_SKIP_FWD / -DBCE_SKIP_MAC leave a phase's LDS traffic out (wrong results) to
+                       // attribute the LDS counters to phases, tools/lds_attribution.sh
         if constexpr (FOLD) {
             // six rows (2..7) on eight waves: whole rows 2..5 on waves 0..3, rows 6 and 7 as halves on waves 4..7
             if (wave < 4) ntt_forward_wave_low8(dct + (2 + wave) * NP, twf, lane, Q);
@@ -1172,6 +1174,7 @@ __device__ __forceinline__ void lat_bootstrap(const PT& P, const bce_gate_desc g
         } else {
             ntt_forward_wave_low8(dct + wave * NP, twf, lane, Q);
         }
+#endif
         if constexpr (WPS >= 4) __builtin_amdgcn_s_setprio(2);
         BCE_PROF_MARK(2);
         if constexpr (PR < R) {
@@ -1190,7 +1193,11 @@ __device__ __forceinline__ void lat_bootstrap(const PT& P, const bce_gate_desc g
 #pragma unroll
             for (u32 l = 0; l < R; ++l) {
                 // FOLD: rows 0, 1 are the accumulator components themselves (< 2Q)
+#ifdef BCE_SKIP_MAC
+                const uint4 d = make_uint4(l + tid, l, tid, 1u);
+#else
                 const uint4 d = *reinterpret_cast<const uint4*>((FOLD && l < 2 ? acc + cb : dct) + l * NP + mpp);
+#endif
                 sp[0] += (u64)d.x * kA[l].x; sp[1] += (u64)d.y * kA[l].y; sp[2] += (u64)d.z * kA[l].z; sp[3] += (u64)d.w * kA[l].w;
                 if constexpr (!AP) {
                     sn[0] += (u64)d.x * kB[l].x; sn[1] += (u64)d.y * kB[l].y; sn[2] += (u64)d.z * kB[l].z; sn[3] += (u64)d.w * kB[l].w;
