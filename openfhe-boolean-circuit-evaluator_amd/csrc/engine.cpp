@@ -1359,7 +1359,17 @@ int bce_dag_run(bce_ctx* c, bce_dag* g, uint32_t instances, uint32_t slot_stride
     // one or two workgroups per CU: two run 512 bootstraps per ~3.1 ms, one runs 256 per ~1.9 ms -- with less work per
     // dependency level than the CUs can hold alone, the shorter bootstrap wins
     int wps = c->dag_wg_per_cu == 1 ? 2 : 4;
-    if (c->dag_wg_per_cu == 0) wps = (items / std::max<u32>(1, g->depth) <= (u64)c->P.cu_count * 3 / 4) ? 2 : 4;
+    if (c->dag_wg_per_cu == 0) {
+        // lower bound of the run under either residency, in units of one bootstrap with a CU to itself: the DAG's longest
+        // chain against the work over the chip's rate.  Two workgroups per CU take 1.6 x as long per bootstrap (3.1 vs
+        // 1.93 ms) and deliver 1.26 x the rate (165 vs 131 k/s); the cheaper bound wins (AES-expanded: K <= 2 one per CU,
+        // K >= 4 two; md5 K = 16 and adder_64 K = 64 one.  Against the earlier rule "work per level <= 3/4 of the CUs":
+        // adder_64 K = 64 97.9 -> 117.9 k/s, AES K = 2 115.7 -> 109.6 k, md5 K = 16 114.0 -> 110.1 k,
+        // profiles/r03_dataflow_vs_steps.jsonl)
+        const double D = (double)std::max<u32>(1, g->depth), W = (double)items, cus = (double)std::max<u32>(1, c->P.cu_count);
+        const double t1 = std::max(D, W / cus), t2 = std::max(1.6 * D, W / (1.26 * cus));
+        wps = t1 <= t2 ? 2 : 4;
+    }
     if (const char* e = std::getenv("BCE_DAG_WPS")) { if (e[0] == '2') wps = 2; else if (e[0] == '4') wps = 4; }
     if (c->P.is64) wps = 2;      // the config-5 kernel: one 1,024-thread workgroup is all a CU's LDS holds
     if (const char* e = std::getenv("BCE_DAG_PLACE")) D.policy = e[0] == '0' ? 0u : 1u;
