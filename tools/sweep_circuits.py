@@ -1,5 +1,6 @@
 """Every circuit under tests/golden/circuits, encrypted on the GPU with the slack-filled bootstrap-depth schedule, K = 3
-random input sets each, against the plaintext evaluation of the same runtime (development aid / robustness sweep)."""
+random input sets each, against the plaintext evaluation of the same runtime -- step by step, then once more replayed as
+one hipGraph (development aid / robustness sweep)."""
 import importlib
 import json
 import os
@@ -50,9 +51,15 @@ def main():
         c.Clock()
         dt = time.time() - t0
         ok = all(c.Outputs(k) == want[k] for k in range(K))
-        bad += 0 if ok else 1
+        # the same evaluation replayed as one hipGraph (Circuit.setGraph): outputs again
+        c.Rearm(); c.setGraph(True)
+        t0 = time.time()
+        c.Clock()
+        dtg = time.time() - t0
+        okg = c.graphActive() and all(c.Outputs(k) == want[k] for k in range(K))
+        bad += 0 if (ok and okg) else 1
         print(json.dumps({"circuit": fname, "bootstraps": info["n_bootstraps"], "steps": len(c.relevel_steps()), "K": K,
-                          "seconds": round(dt, 3), "correct": ok}), flush=True)
+                          "seconds": round(dt, 3), "correct": ok, "graph_seconds": round(dtg, 3), "graph_correct": okg}), flush=True)
         c.close()
     print("SWEEP %s" % ("ok" if bad == 0 else "%d circuits WRONG" % bad))
     sys.exit(1 if bad else 0)
