@@ -172,6 +172,14 @@ def test_predicted_gate_sharding_curve_is_consistent(bce):
     assert all(0 < x["efficiency"] <= 1.0 for x in rows)
     assert rows[1]["crossing_outputs_per_instance"] > 0 and rows[2]["crossing_outputs_per_instance"] >= rows[1]["crossing_outputs_per_instance"]
     assert pred.launch_ms(256) < pred.launch_ms(257) < pred.launch_ms(512) < pred.launch_ms(513)
+    # weak form (`shard_gates_weak.predicted`): K blocks PER GPU; each world's row carries K x world instances, the
+    # throughput ratio is what `speedup_vs_1` holds and it cannot exceed the number of GPUs
+    w = pred.predict_gate_sharding(os.path.join(CIRCUITS, "adder_64bit.txt"), False, 64, worlds=(1, 2, 4), weak=True)
+    assert w["scaling"] == "weak" and [x["instances"] for x in w["rows"]] == [64, 128, 256]
+    assert w["rows"][0]["speedup_vs_1"] == 1.0
+    for x in w["rows"]:
+        assert 0 < x["efficiency"] <= 1.0 and x["speedup_vs_1"] <= x["gpus"] + 1e-9
+    assert w["rows"][2]["gate_bootstraps_per_s"] > w["rows"][1]["gate_bootstraps_per_s"] > w["rows"][0]["gate_bootstraps_per_s"]
 
 
 def test_bench_cpu_baseline_walks_the_reference_s_rounds(orc):
