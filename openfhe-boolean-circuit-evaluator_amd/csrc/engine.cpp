@@ -180,8 +180,11 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     c->dR = digit_count((double)q, (double)baseR);
     c->is64 = Q >= (1ull << 28);
     c->wbytes = c->is64 ? 8 : 4;
-    if (c->dG < 3 || c->dG > 4 || (N == 2048 && c->dG != 3)) { g_create_error = "gadget digit count must be 3 or 4 (3 for N = 2048)"; return BCE_ERR_UNSUPPORTED; }
-    if (c->is64 && !(c->dG == 3 || (c->dG == 4 && N == 512))) { g_create_error = "64-bit path: gadget digit count must be 3"; return BCE_ERR_UNSUPPORTED; }
+    // four gadget digits on N >= 1024 with a modulus of 28..30 bits (STD256, STD256_OPT: N = 2048, 29-bit Q, base 2^8): the
+    // integer 64-bit kernel with 32-bit digit rows (kernels64.hip, NARROW)
+    const bool narrow64 = c->is64 && c->dG == 4 && N >= 1024 && Q < (1ull << 31);
+    if (c->dG < 3 || c->dG > 4 || (N == 2048 && c->dG != 3 && !narrow64)) { g_create_error = "gadget digit count must be 3 or 4 (N = 2048: 3, or 4 with a ring modulus of 28..30 bits)"; return BCE_ERR_UNSUPPORTED; }
+    if (c->is64 && !(c->dG == 3 || (c->dG == 4 && N == 512) || narrow64)) { g_create_error = "64-bit path: four gadget digits need N = 512 or a ring modulus below 2^31"; return BCE_ERR_UNSUPPORTED; }
     if (c->qKS > 0xFFFFFFFFull) { g_create_error = "qKS must fit 32 bits"; return BCE_ERR_UNSUPPORTED; }
     c->psi = min_primitive_root(Q, 2ull * N);
 
@@ -297,6 +300,7 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         // integer kernel (development / parity knob)
         const char* fp = std::getenv("BCE_FP64");
         P.fp64 = (Q < (1ull << 39) && !(fp && fp[0] == '0')) ? 1 : 0;
+        if (narrow64) P.fp64 = 0;   // no doubles kernel for this class: the key words stay 64-bit integers
         // includes the 16 KiB twiddle mirror of the 8-wave N = 2048 kernel (n <= ~1020 there)
         if (blind_rotate64_lds_bytes(P) > 160 * 1024) { g_create_error = "64-bit path: polynomials (+ twiddle mirror) do not fit the 160 KiB LDS"; return BCE_ERR_UNSUPPORTED; }
         P.Qd = (double)Q;

@@ -140,6 +140,7 @@ hipError_t launch_tail(const DevParams& P, const bce_gate_desc* d_descs, u32 n_d
 
 // 64-bit-modulus counterparts (kernels64.hip)
 size_t blind_rotate64_lds_bytes(const DevParams& P);
+bool blind_rotate64_narrow(const DevParams& P);   // integer 64-bit kernel with 32-bit digit rows (four gadget digits, N >= 1024, Q < 2^31)
 // *tail_fused (optional) is set when the launched kernel also ran the tail (then dbg_lweN / dbg_ks are its debug outputs)
 hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances,
                                  u32 slot_stride, u64* acc_out, hipStream_t s, u32* dbg_lweN = nullptr, u32* dbg_ks = nullptr,

@@ -12,6 +12,8 @@
 
 #include <utility>
 
+#include <type_traits>
+
 #include "kernels.hpp"
 #include "phase_prof.hpp"
 
@@ -92,15 +94,25 @@ __device__ __forceinline__ u32 elem_j(u32 lane, int r) {
     constexpr int LE = Cfg<LOGN>::LE;
     return ((lane >> LO) << (LO + LE)) | ((u32)r << LO) | (lane & ((1u << LO) - 1u));
 }
-template <int LOGN, int LO>
-__device__ __forceinline__ void load_pass(const u64* poly, u32 lane, u64 (&x)[Cfg<LOGN>::E]) {
+// LW: the LDS word of the row (u64, or u32 for the digit rows of the narrow build: values below 2^32 only)
+template <int LOGN, int LO, typename LW>
+__device__ __forceinline__ void load_pass(const LW* poly, u32 lane, u64 (&x)[Cfg<LOGN>::E]) {
 #pragma unroll
     for (int r = 0; r < Cfg<LOGN>::E; ++r) x[r] = poly[phys(elem_j<LOGN, LO>(lane, r))];
 }
-template <int LOGN, int LO>
-__device__ __forceinline__ void store_pass(u64* poly, u32 lane, const u64 (&x)[Cfg<LOGN>::E]) {
+template <int LOGN, int LO, typename LW>
+__device__ __forceinline__ void store_pass(LW* poly, u32 lane, const u64 (&x)[Cfg<LOGN>::E]) {
 #pragma unroll
-    for (int r = 0; r < Cfg<LOGN>::E; ++r) poly[phys(elem_j<LOGN, LO>(lane, r))] = x[r];
+    for (int r = 0; r < Cfg<LOGN>::E; ++r) poly[phys(elem_j<LOGN, LO>(lane, r))] = (LW)x[r];
+}
+// [0, Q) from any 64-bit value (the quotient estimate is low by at most 2)
+template <int E>
+__device__ __forceinline__ void normalise(u64 (&x)[E], u64 Q, u64 mu64) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const u64 v = x[r] - __umul64hi(x[r], mu64) * Q;
+        x[r] = csub(csub(v, 2 * Q), Q);
+    }
 }
 
 // forward (Cooley-Tukey) stage on index bit B, no correction: values grow by < 2Q per stage
@@ -154,30 +166,28 @@ __device__ __forceinline__ void inv_stages(u64 (&x)[Cfg<LOGN>::E], u32 lane, con
     }
 }
 
-// forward NTT by one wave in LDS; input < 2Q, output bit-reversed, < (2*LOGN+2) Q unless NORM
-template <int LOGN, bool NORM>
-__device__ __forceinline__ void ntt_forward_wave(u64* poly, const ulonglong2* tw, u32 lane, u64 Q, u64 mu64) {
+// forward NTT by one wave in LDS; input < 2Q, output bit-reversed, < (2*LOGN+2) Q unless NORM.
+// Rows of 32-bit words (narrow build, Q < 2^31): every store is of normalised values, NORM is implied.
+template <int LOGN, bool NORM, typename LW>
+__device__ __forceinline__ void ntt_forward_wave(LW* poly, const ulonglong2* tw, u32 lane, u64 Q, u64 mu64) {
     using C = Cfg<LOGN>;
+    constexpr bool NARROW = sizeof(LW) == 4;
     u64 x[C::E];
     load_pass<LOGN, 6>(poly, lane, x);
     fwd_stages<LOGN, 6, LOGN - 1, 6>(x, lane, tw, Q);
+    if constexpr (NARROW) normalise<C::E>(x, Q, mu64);
     store_pass<LOGN, 6>(poly, lane, x);
     wave_sync();
     load_pass<LOGN, C::F2LO>(poly, lane, x);
     fwd_stages<LOGN, C::F2LO, 5, C::F2LO>(x, lane, tw, Q);
     if constexpr (C::F2LO > 0) {
+        if constexpr (NARROW) normalise<C::E>(x, Q, mu64);
         store_pass<LOGN, C::F2LO>(poly, lane, x);
         wave_sync();
         load_pass<LOGN, 0>(poly, lane, x);
         fwd_stages<LOGN, 0, C::F2LO - 1, 0>(x, lane, tw, Q);
     }
-    if constexpr (NORM) {
-#pragma unroll
-        for (int r = 0; r < C::E; ++r) {
-            u64 v = x[r] - __umul64hi(x[r], mu64) * Q;
-            x[r] = csub(csub(v, 2 * Q), Q);
-        }
-    }
+    if constexpr (NORM || NARROW) normalise<C::E>(x, Q, mu64);
     store_pass<LOGN, 0>(poly, lane, x);
     wave_sync();
 }
@@ -221,16 +231,22 @@ __device__ __forceinline__ u32 gate_const(u32 op, u32 q) {
 
 // NBUF_ / NPRE_: depth of the key-row software pipeline (items in flight / requested before the transforms);
 // the defaults are the deepest that compile without scratch at N = 2048 (GINX items carry two keys' rows)
-template <int LOGN, int DG, bool AP, u32 NBUF_ = (AP ? 3 : 2), u32 NPRE_ = (AP ? 2 : 1)>
+// NARROW: the R digit rows are 32-bit words (Q < 2^31: a digit + Q and every normalised transform value fit), the inverse
+// transforms get a scratch of their own -- what lets N = 2048 with FOUR gadget digits (STD256, STD256_OPT: 29-bit Q, base 2^8)
+// into the 160 KiB of LDS: 2 x 17 KiB accumulator + 8 x 8.5 KiB digit rows + 2 x 17 KiB scratch instead of 10 x 17 KiB.
+template <int LOGN, int DG, bool AP, u32 NBUF_ = (AP ? 3 : 2), u32 NPRE_ = (AP ? 2 : 1), bool NARROW = false>
 __global__ __launch_bounds__(128 * DG) void k_blind_rotate64(DevParams P, const bce_gate_desc* __restrict__ descs, u32 n_desc,
                                                               u32 slot_stride, u64* __restrict__ acc_out, u32* /*dbg_lweN: no fused tail*/, u32* /*dbg_ks*/) {
     using C = Cfg<LOGN>;
     constexpr int N = C::N, NP = C::NP, E = C::E;
     constexpr u32 R = 2 * DG, T = 64 * R;
     extern __shared__ __align__(16) u64 smem64[];
+    using DW = std::conditional_t<NARROW, u32, u64>;
     u64* acc = smem64;            // [2][NP] EVALUATION domain, [0, Q)
-    u64* dct = acc + 2 * NP;      // [R][NP]
-    u32* av = reinterpret_cast<u32*>(dct + R * NP);
+    DW* dct = reinterpret_cast<DW*>(acc + 2 * NP);      // [R][NP]
+    // exchange rows of the two inverse transforms: the digit rows themselves, or (narrow build) two 64-bit rows behind them
+    u64* inv_tmp = reinterpret_cast<u64*>(NARROW ? dct + R * NP : dct);
+    u32* av = NARROW ? reinterpret_cast<u32*>(inv_tmp + 2 * NP) : reinterpret_cast<u32*>(dct + R * NP);
     const ulonglong2* __restrict__ tw = P.tw64;
 
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -331,7 +347,7 @@ __global__ __launch_bounds__(128 * DG) void k_blind_rotate64(DevParams P, const 
         if constexpr (NPRE >= 2) request(std::integral_constant<u32, 1>{});
         if (wave < 2) {
             u64 x[E];
-            ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, tw, lane_v, Q, ninv, x);
+            ntt_inverse_wave<LOGN>(acc + wave * NP, inv_tmp + wave * NP, tw, lane_v, Q, ninv, x);
             const int gsh = 64 - (int)P.gBits;
             const u64 Qh = Q >> 1;
 #pragma unroll
@@ -342,14 +358,14 @@ __global__ __launch_bounds__(128 * DG) void k_blind_rotate64(DevParams P, const 
                 for (u32 l = 0; l < (u32)DG; ++l) {
                     long long rem = (long long)((u64)d << gsh) >> gsh;
                     d = (d - rem) >> P.gBits;
-                    dct[(2 * l + wave) * NP + pj] = (u64)(rem + (long long)Q);  // in (Q - B/2, Q + B/2)
+                    dct[(2 * l + wave) * NP + pj] = (DW)(u64)(rem + (long long)Q);  // in (Q - B/2, Q + B/2)
                 }
             }
         }
         BCE_PROF_MARK(0);
         block_sync_lds();
         BCE_PROF_MARK(1);
-        ntt_forward_wave<LOGN, false>(dct + wave * NP, tw, lane_v, Q, P.mu64);
+        ntt_forward_wave<LOGN, NARROW>(dct + wave * NP, tw, lane_v, Q, P.mu64);
         BCE_PROF_MARK(2);
         block_sync_lds();
         BCE_PROF_MARK(3);
@@ -367,7 +383,13 @@ __global__ __launch_bounds__(128 * DG) void k_blind_rotate64(DevParams P, const 
                 U128 sp[2] = {{0, 0}, {0, 0}}, sn[2] = {{0, 0}, {0, 0}};
 #pragma unroll
                 for (u32 l = 0; l < R; ++l) {
-                    const ulonglong2 d = *reinterpret_cast<const ulonglong2*>(dct + l * NP + pp);
+                    ulonglong2 d;
+                    if constexpr (NARROW) {
+                        const uint2 dn = *reinterpret_cast<const uint2*>(dct + l * NP + pp);
+                        d = make_ulonglong2(dn.x, dn.y);
+                    } else {
+                        d = *reinterpret_cast<const ulonglong2*>(dct + l * NP + pp);
+                    }
                     const ulonglong2 kp = kb[k % NBUF][l];
                     mac128(sp[0], d.x, kp.x);
                     mac128(sp[1], d.y, kp.y);
@@ -416,7 +438,7 @@ __global__ __launch_bounds__(128 * DG) void k_blind_rotate64(DevParams P, const 
     BCE_PROF_FLUSH();
     if (wave < 2) {
         u64 x[E];
-        ntt_inverse_wave<LOGN>(acc + wave * NP, dct + wave * NP, tw, lane, Q, ninv, x);
+        ntt_inverse_wave<LOGN>(acc + wave * NP, inv_tmp + wave * NP, tw, lane, Q, ninv, x);
         u64* out = acc_out + ((size_t)blockIdx.x * 2 + wave) * N;
 #pragma unroll
         for (int r = 0; r < E; ++r) out[((u32)r << 6) | lane] = x[r];
@@ -1372,8 +1394,14 @@ hipError_t launch_words_u64_f64(u64* words, size_t count, int to_double, hipStre
     return hipGetLastError();
 }
 
+// the narrow build of the integer kernel (32-bit digit rows): four gadget digits on N >= 1024, Q < 2^31
+bool blind_rotate64_narrow(const DevParams& P) {
+    return P.is64 && !P.fp64 && P.dG == 4 && P.logN >= 10 && P.Q64 < (1ull << 31);
+}
+
 size_t blind_rotate64_lds_bytes(const DevParams& P) {
     const size_t N = P.N, NP = N + (N >> 6) * 4, R = 2 * P.dG;
+    if (blind_rotate64_narrow(P)) return 2 * NP * sizeof(u64) + R * NP * sizeof(u32) + 2 * NP * sizeof(u64) + ((P.n + 1 + 3) & ~3u) * sizeof(u32);
     // the 8-wave double-precision kernel (N = 2048, 3 gadget digits) also mirrors the first 1024 twiddle entries
     const size_t mirror = (P.fp64 && P.logN == 11 && P.dG == 3) ? 1024 * sizeof(double2) : 0;
     return (2 + R) * NP * sizeof(u64) + ((P.n + 1 + 3) & ~3u) * sizeof(u32) + mirror;
@@ -1435,6 +1463,10 @@ hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32
         }
     } else if (P.dG == 4 && P.logN == 9) {
         kern = ap ? w64::k_blind_rotate64<9, 4, true> : w64::k_blind_rotate64<9, 4, false>;
+    } else if (blind_rotate64_narrow(P)) {
+        // STD256 / STD256_OPT (N = 2048) and their N = 1024 siblings: 32-bit digit rows
+        if (P.logN == 11) kern = ap ? w64::k_blind_rotate64<11, 4, true, 2, 1, true> : w64::k_blind_rotate64<11, 4, false, 1, 0, true>;
+        else kern = ap ? w64::k_blind_rotate64<10, 4, true, 3, 2, true> : w64::k_blind_rotate64<10, 4, false, 2, 1, true>;
     }
     if (!kern || (P.fold && !(P.fp64 && P.dG == 3 && P.logN == 11))) return hipErrorInvalidValue;  // folded key: N = 2048 fp64 kernels only
     const size_t lds = blind_rotate64_lds_bytes(P);

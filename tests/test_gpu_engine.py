@@ -248,8 +248,8 @@ def test_errors_are_reported_not_thrown(bce):
     with pytest.raises(bce.BceError) as e:
         c.EvalGates([(bce.AND, 0, 1, 2)])
     assert e.value.code == bce.ERR_POOL
-    with pytest.raises(bce.BceError) as e:
-        bce.BinFHEContext(bce.STD256, bce.GINX)   # N = 2048 with 4 gadget digits: not instantiated
+    with pytest.raises(bce.BceError) as e:           # N = 2048 with four gadget digits needs a ring modulus below 2^31 (STD256 has
+        bce.BinFHEContext(method=bce.GINX, custom=(16, 2048, 1024, 68719403009, 1 << 14, 128, 1 << 9, 32))   # one); 36 bits: no kernel
     assert e.value.code == bce.ERR_UNSUPPORTED
     with pytest.raises(bce.BceError) as e:           # ring modulus of 40 bits or more (1099511630849 = 1 mod 1024, prime): no kernel
         bce.BinFHEContext(method=bce.GINX, custom=(16, 512, 512, 1099511630849, 1 << 14, 128, 1 << 14, 23))
@@ -442,6 +442,54 @@ def test_q64_custom_context_bit_exact_stages(bce, orc, method, arith, dg, N, mon
         assert np.array_equal(ks[i], r_ks)
         assert np.array_equal(out[i], o.modswitch_final(r_ks))
         assert o.decrypt(out[i]) == _truth(g, a, b)
+
+
+def _custom_narrow(orc, N):
+    L = orc.lib()
+    Q = L.bo_previous_prime(L.bo_first_prime(29, 2 * N), 2 * N)    # the ring modulus of STD256 when N = 2048
+    #       n   N  q          Q  qKS      baseKS baseG   baseR
+    return (24, N, min(2 * N, 2048), Q, 1 << 14, 128,  1 << 8, 46)    # base 2^8: four gadget digits; baseR 46 as in STD256
+
+
+@pytest.mark.parametrize("N", [1024, 2048])
+@pytest.mark.parametrize("method", ["GINX", "AP"])
+def test_four_digit_29_bit_modulus_narrow_kernel_bit_exact_stages(bce, orc, method, N):
+    """STD256's parameter class (29-bit Q >= 2^28, four gadget digits, N = 2048; and its N = 1024 sibling): the integer
+    64-bit kernel with 32-bit digit rows (kernels64.hip NARROW -- ten 64-bit rows of N = 2048 would not fit the LDS).
+    Small n so that both methods' keys are quick: NTT, keygen (every key word) and every stage of EvalBinGate against the
+    oracle, both methods (AP with OpenFHE's base 46 for this set: the digit of a is taken by division)."""
+    params = _custom_narrow(orc, N)
+    o = orc.Oracle(method=getattr(orc, method), custom=params)
+    o.keygen(2718)
+    c = bce.BinFHEContext(method=getattr(bce, method), custom=params)
+    assert o.params == c.params and (1 << 28) <= o.params["Q"] < (1 << 29) and o.params["dG"] == 4
+    assert c.forward_transforms_per_step() == 8
+    rng = np.random.default_rng(5)
+    polys = rng.integers(0, o.params["Q"], size=(3, o.N), dtype=np.uint64)
+    fwd = c.debug_ntt(polys, inverse=False)
+    for k in range(3):
+        assert np.array_equal(fwd[k], o.ntt_forward(polys[k]))
+    assert np.array_equal(c.debug_ntt(fwd, inverse=True), polys)
+    c.KeyGen(2718)
+    assert np.array_equal(c.export_bsk(), o.bsk()) and np.array_equal(c.export_ksk(), o.ksk())
+    cases = _gate_cases(o, base=70)
+    nb = len(cases)
+    c.pool_reserve(3 * nb)
+    c.lwe_write(np.arange(2 * nb, dtype=np.uint32), np.concatenate([np.stack([ca, cb]) for (_, _, _, ca, cb) in cases]))
+    descs = [(g, 2 * i, 2 * i + 1, 2 * nb + i) for i, (g, _, _, _, _) in enumerate(cases)]
+    acc, lweN, ks = c.debug_eval_stages(descs)
+    out = c.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32))
+    for i, (g, a, b, ca, cb) in enumerate(cases):
+        r_acc = o.blind_rotate(g, o.gate_prep(g, ca, cb))
+        assert np.array_equal(acc[i], r_acc), "narrow kernel accumulator differs, case %d" % i
+        r_lweN = o.extract_modswitch(r_acc)
+        assert np.array_equal(lweN[i], r_lweN)
+        r_ks = o.keyswitch(r_lweN)
+        assert np.array_equal(ks[i], r_ks)
+        assert np.array_equal(out[i], o.modswitch_final(r_ks))
+        assert o.decrypt(out[i]) == _truth(g, a, b)
+    o.close()
+    c.close()
 
 
 @pytest.mark.parametrize("method", ["GINX"])
@@ -654,12 +702,13 @@ def test_std128_saturated_launch_of_distinct_gates_equals_oracle(std128, bce):
         assert o.decrypt(got[i]) == want
 
 
-@pytest.mark.parametrize("ps,fwd", [("STD128", 6), ("STD192_OPT", 4), ("STD128_APOPT", 6), ("MEDIUM", 6)])
+@pytest.mark.parametrize("ps,fwd", [("STD128", 6), ("STD192_OPT", 4), ("STD128_APOPT", 6), ("MEDIUM", 6), ("STD256", 8), ("STD256_OPT", 8)])
 def test_other_parameter_sets_of_the_table_same_seed_keys(bce, orc, ps, fwd):
     """The remaining rows of OpenFHE's parameter table that the kernels cover, GINX: STD128 (n = 512) runs the folded
     split-transform kernel like STD128_OPT, STD192_OPT (n = 805, qKS = 2^15) the folded N = 2048 doubles kernel;
     STD128_APOPT (27-bit Q, 3 digits base 2^9: gadget not exact) and MEDIUM (28-bit Q: non-lazy path) stay on the
-    one-wave-per-transform kernel with the plain key.  Engine keygen from the seed the oracle uses (keygen parity is
+    one-wave-per-transform kernel with the plain key; STD256 / STD256_OPT (N = 2048, 29-bit Q, FOUR digits base 2^8, q = 2048)
+    the integer 64-bit kernel with 32-bit digit rows.  Engine keygen from the seed the oracle uses (keygen parity is
     established above), 12 gates on distinct ciphertexts vs the oracle's batched evaluation."""
     o = orc.Oracle(getattr(orc, ps), orc.GINX)
     o.keygen(1618)
