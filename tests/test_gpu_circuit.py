@@ -437,3 +437,25 @@ def test_bristol_fashion_constants_mand_buses_encrypted(bce, orc, toy_cc, tmp_pa
     q = o.params["q"]
     assert not regs[5][:-1].any() and regs[5][-1] == q // 4 and not regs[6].any()
     assert np.array_equal(regs[9], o.eval_bingate(orc.AND, regs[7], regs[5]))
+
+
+def test_adder_32bit_std256_encrypted_lock_step(bce):
+    """STD256 (N = 2048, 29-bit Q, four gadget digits, q = 2048): the integer 64-bit kernel with 32-bit digit rows under the
+    circuit runtime -- adder_32bit, the reference's srand(test_ix) operands (src/test_adder.cpp:180-190), K = 4 in lock-step
+    on the bootstrap-depth schedule, keys from OS entropy, inputs BOOTSTRAPPED like the reference's cc.Encrypt"""
+    cc = bce.BinFHEContext(bce.STD256, bce.GINX)
+    cc.KeyGen(None)
+    c = bce.Circuit(cc)
+    c.ReadBristol(os.path.join(CIRCUITS, "adder_32bit.txt"))
+    K = 4
+    c.setInstances(K)
+    c.Reset(); c.setEncrypted(True); c.setRelevel(True)
+    cases = [kat.adder_case(t, 32) for t in range(K)]
+    for k, (ins, _) in enumerate(cases):
+        c.SetInput(ins, instance=k)
+    c.Clock()
+    for k, (_, want) in enumerate(cases):
+        assert c.Outputs(k)[0] == want, "instance %d" % k
+    assert c.stats()["bootstraps"] == K * 310
+    c.close()
+    cc.close()
