@@ -484,20 +484,22 @@ def main():
                         "insts_per_bootstrap": vm["insts_per_bootstrap"], "ns_per_wave_inst_per_simd": vm["ns_per_wave_inst_per_simd"],
                         "floor_ms_per_launch": vm["insts_per_bootstrap"] * per_launch * vm["ns_per_wave_inst_per_simd"] / vm["simds"] / 1e6,
                         "source": vm_src}
+            # binding roof on top, the HBM figures below it
+            for k in ("bound", "what", "achieved", "peak", "unit", "frac"):
+                roof[k] = valu_obj[k]
+            roof["valu"] = valu_obj
+            roof["hbm"] = hbm
+            for k in ("bytes_per_bootstrap", "algorithmic_bytes_per_launch", "compulsory_bytes_per_launch", "counter_traffic_bytes_per_launch",
+                      "counter_traffic_frac_of_peak", "wasted_traffic_ratio", "traffic_source"):
+                roof.pop(k, None)
             if not cfg5:
-                # binding roof on top, the HBM figures below it
-                for k in ("bound", "what", "achieved", "peak", "unit", "frac"):
-                    roof[k] = valu_obj[k]
-                roof["valu"] = valu_obj
-                roof["hbm"] = hbm
-                for k in ("bytes_per_bootstrap", "algorithmic_bytes_per_launch", "compulsory_bytes_per_launch", "counter_traffic_bytes_per_launch",
-                          "counter_traffic_frac_of_peak", "wasted_traffic_ratio", "traffic_source"):
-                    roof.pop(k, None)
                 roof["note"] = ("bound = integer-VALU issue (what limits this kernel); `hbm` keeps the byte convention (frac > 1: the 62.8 MiB key is "
                                 "served from L2 / Infinity Cache across the batch), the counter-based traffic and the wasted-traffic ratio")
             else:
-                roof["valu"] = valu_obj
-                roof["note"] = "bound = HBM by the byte convention (AP keys are digit-selected per bootstrap and hardly shared); `valu` = fp64 issue, the next roof"
+                roof["note"] = ("bound = fp64 issue: with every bootstrap of a launch on the SAME keys (no HBM traffic to speak of) this kernel is only 8 % "
+                                "faster (tools/ap_key_locality.py STD192, profiles/r03_cfg5_key_locality.log), so the bytes in `hbm` -- AP keys are "
+                                "digit-selected per bootstrap and hardly shared -- are not what holds it; both fractions sit near 0.6 because the part runs "
+                                "it at 95 % of its board power")
         if R["dataflow"]:
             roof["dataflow"] = R["dag_last_run"]
         out = {
