@@ -218,3 +218,27 @@ def test_random_netlists_dataflow_equals_step_schedule_and_plaintext(bce, tmp_pa
         c.close()
     cc.set_encrypt_seed(None)
     assert np.array_equal(snap["steps"], snap["dataflow"])
+
+
+def test_sha256_dataflow_four_reference_vectors(bce, std):
+    """The largest DAG of the BASELINE configs through the persistent kernel: new-format sha256, 354,505 tasks x 4 instances
+    (1.4 M bootstraps, 9,055 dependency levels) in ONE launch; the four vectors of sha-256-test.txt must come out."""
+    _, cc = std
+    c = bce.Circuit(cc)
+    c.ReadBristol(os.path.join(CIRCUITS, "sha256_new.txt"), new_flag=True)
+    vecs = kat.hash_vectors("sha-256-test.txt")
+    c.setInstances(len(vecs))
+    c.Reset(); c.setEncrypted(True); c.setRelevel(True); c.setDataflow(True)
+    for k, (inhex, outhex) in enumerate(vecs):
+        c.SetInput(kat.sha256_new_case(inhex, outhex)[0], instance=k)
+    assert c.dataflowActive()
+    t0 = cc.timing()
+    c.Clock()
+    t1 = cc.timing()
+    for k, (inhex, outhex) in enumerate(vecs):
+        assert c.Outputs(k)[0] == kat.sha256_new_case(inhex, outhex)[1], "sha-256 vector %d" % k
+    assert t1["bootstraps"] - t0["bootstraps"] == 354505 * len(vecs)
+    assert t1["blind_rotate_launches"] - t0["blind_rotate_launches"] == 1
+    last = cc.dag_last_run()
+    assert last["done"] == 354505 * len(vecs) and last["abort"] == 0
+    c.close()
