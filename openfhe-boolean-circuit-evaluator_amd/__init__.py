@@ -60,7 +60,7 @@ ENGINE_SYMBOLS = [
     "bce_keygen", "bce_import_keys", "bce_import_keys_eval", "bce_export_bsk_eval", "bce_import_keys_file", "bce_export_keys_file", "bce_bsk_words", "bce_ksk_words", "bce_export_sk", "bce_export_bsk",
     "bce_export_ksk", "bce_pool_reserve", "bce_pool_slots", "bce_lwe_write", "bce_lwe_read",
     "bce_encrypt_bits", "bce_set_encrypt_seed", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize",
-    "bce_timing_reset", "bce_timing_get", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_forward_transforms_per_step", "bce_launch_capacity", "bce_rccl_available", "bce_rccl_version", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
+    "bce_timing_reset", "bce_timing_get", "bce_timing_set_events", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_forward_transforms_per_step", "bce_launch_capacity", "bce_rccl_available", "bce_rccl_version", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
     "bce_rccl_shutdown", "bce_debug_eval_stages", "bce_debug_ntt",
     "bce_dag_supported", "bce_dag_create", "bce_dag_run", "bce_dag_destroy", "bce_dag_set_limits", "bce_dag_last_run", "bce_dag_debug_block_task",
     "bce_plan_create", "bce_plan_run_step", "bce_plan_run", "bce_plan_destroy",
@@ -117,6 +117,7 @@ def lib():
     L.bce_synchronize.argtypes = [vp]
     L.bce_timing_reset.argtypes = [vp]
     L.bce_timing_get.argtypes = [vp, C.POINTER(Timing)]
+    L.bce_timing_set_events.argtypes = [vp, i32]
     L.bce_bytes_per_bootstrap.argtypes = [vp]
     L.bce_bytes_per_bootstrap.restype = u64
     L.bce_bytes_per_bootstrap_parts.argtypes = [vp, C.POINTER(u64)]
@@ -303,6 +304,10 @@ class BinFHEContext:
 
     def timing_reset(self):
         self._ck(self._L.bce_timing_reset(self.h))
+
+    def timing_set_events(self, on):
+        """per-launch HIP events on (default) / off (counters only; nothing between dependent kernels on the device timeline)"""
+        self._ck(self._L.bce_timing_set_events(self.h, int(bool(on))))
 
     def timing(self):
         t = Timing()

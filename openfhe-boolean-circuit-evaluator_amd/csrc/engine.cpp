@@ -105,6 +105,7 @@ struct bce_ctx {
     void* d_acc = nullptr;
     size_t acc_cap = 0;  // bootstraps
     u64* d_tail_partial = nullptr;  // partial key-switch sums (kernels.hip, k_tail_gather)
+    bool events_on = true;                 // per-launch HIP events (bce_timing_set_events): off = counters only, no event packets between dependent kernels
     u32 *d_io = nullptr, *h_io = nullptr;  // staging of bce_lwe_read for scattered slots (device gather + one pinned copy)
     size_t io_cap = 0;
     size_t tail_cap = 0;            // u64 words
@@ -548,20 +549,23 @@ int launch_bootstraps(bce_ctx* c, const bce_gate_desc* dd, u32 n, u32 instances,
     const size_t nb = (size_t)n * instances;
     int kid = BCE_BR_WORD64;
     bool tail_fused = false;
+    const bool events = timed && c->events_on;
     EventPair e0{};
-    if (timed) { e0 = get_events(c, 0); hipEventRecord(e0.a, c->stream); }
+    if (events) { e0 = get_events(c, 0); hipEventRecord(e0.a, c->stream); }
     if (c->is64) HIP_TRY(c, launch_blind_rotate64(c->P, dd, n, instances, slot_stride, static_cast<u64*>(d_acc), c->stream, d_lweN, d_ks, &tail_fused));
     else HIP_TRY(c, launch_blind_rotate(c->P, dd, n, instances, slot_stride, static_cast<u32*>(d_acc), c->stream, &kid, d_lweN, d_ks, &tail_fused));
-    if (timed) {
+    if (events) {
         hipEventRecord(e0.b, c->stream);
         e0.kind = kid;
         c->pending.push_back(e0);
+    }
+    if (timed) {
         c->timing.br_launches[kid] += 1;
         c->timing.br_bootstraps[kid] += nb;
     }
     if (!tail_fused) {
         EventPair e1{};
-        if (timed) {
+        if (events) {
             e1 = get_events(c, BCE_BR_KERNELS);  // kind >= BCE_BR_KERNELS: tail
             hipEventRecord(e1.a, c->stream);
         }
@@ -577,7 +581,7 @@ int launch_bootstraps(bce_ctx* c, const bce_gate_desc* dd, u32 n, u32 instances,
             }
         }
         HIP_TRY(c, launch_tail(c->P, dd, n, instances, slot_stride, d_acc, d_partial ? d_partial : c->d_tail_partial, d_lweN, d_ks, c->stream));
-        if (timed) { hipEventRecord(e1.b, c->stream); c->pending.push_back(e1); }
+        if (events) { hipEventRecord(e1.b, c->stream); c->pending.push_back(e1); }
     } else if (timed) {
         c->timing.fused_tail_launches += 1;
     }
@@ -1411,6 +1415,12 @@ int bce_timing_reset(bce_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_timing(c);
     c->timing = bce_timing{};
+    return BCE_OK;
+}
+
+int bce_timing_set_events(bce_ctx* c, int on) {
+    if (!c) return BCE_ERR_ARG;
+    c->events_on = on != 0;
     return BCE_OK;
 }
 

@@ -186,3 +186,34 @@ def test_random_netlists_graph_equals_step_schedule_and_plaintext(bce, tmp_path,
         c.close()
     cc.set_encrypt_seed(None)
     assert np.array_equal(snap["steps"], snap["graph"])
+
+
+def test_events_off_counts_without_timing_and_leaves_the_same_ciphertexts(bce, std):
+    """bce_timing_set_events(0): no HIP event between dependent kernels -- launches and bootstraps still counted, the
+    millisecond fields stand still, results unchanged"""
+    _, cc = std
+    rng = np.random.default_rng(31)
+    n_in, n_tasks = 8, 40
+    tasks = _random_ssa_dag(bce, rng, n_in, n_tasks, window=10)
+    levels = _levels(tasks)
+    stride = n_in + n_tasks
+    cc.pool_reserve(2 * stride)
+    bits = rng.integers(0, 2, n_in).astype(np.uint8)
+    cc.set_encrypt_seed(SEED)
+    cc.Encrypt(bits, np.arange(n_in), enc_index_base=40)
+    cc.Encrypt(bits, np.arange(n_in) + stride, enc_index_base=40)
+    cc.set_encrypt_seed(None)
+    for level in levels:
+        cc.EvalGates(level)
+    want = cc.lwe_read(np.arange(stride, dtype=np.uint32))
+    cc.timing_set_events(False)
+    try:
+        t0 = cc.timing()
+        for level in levels:
+            cc.EvalGates([(op, a + stride, b + stride, o + stride, n0, n1) for (op, a, b, o, n0, n1) in level])
+        t1 = cc.timing()
+    finally:
+        cc.timing_set_events(True)
+    assert np.array_equal(cc.lwe_read(np.arange(stride, 2 * stride, dtype=np.uint32)), want)
+    assert t1["bootstraps"] - t0["bootstraps"] == n_tasks and t1["blind_rotate_launches"] - t0["blind_rotate_launches"] == len(levels)
+    assert t1["blind_rotate_ms"] == t0["blind_rotate_ms"] and t1["tail_ms"] == t0["tail_ms"]

@@ -139,6 +139,7 @@ def perf(cc, name, Ks, modes):
                 c.setDataflow(True)
             if mode.startswith("graph"):
                 c.setGraph(True)
+            cc.timing_set_events(not mode.endswith("noevents"))
             for k in range(K):
                 c.SetInput(ins[k], instance=k)
             c.Clock()
