@@ -551,11 +551,12 @@ int launch_bootstraps(bce_ctx* c, const bce_gate_desc* dd, u32 n, u32 instances,
     bool tail_fused = false;
     const bool events = timed && c->events_on;
     EventPair e0{};
-    if (events) { e0 = get_events(c, 0); hipEventRecord(e0.a, c->stream); }
-    if (c->is64) HIP_TRY(c, launch_blind_rotate64(c->P, dd, n, instances, slot_stride, static_cast<u64*>(d_acc), c->stream, d_lweN, d_ks, &tail_fused));
-    else HIP_TRY(c, launch_blind_rotate(c->P, dd, n, instances, slot_stride, static_cast<u32*>(d_acc), c->stream, &kid, d_lweN, d_ks, &tail_fused));
+    // the timestamps ride on the kernels' own dispatches (LaunchEvents): no event packet between dependent launches
+    LaunchEvents le0{};
+    if (events) { e0 = get_events(c, 0); le0 = LaunchEvents{e0.a, e0.b}; }
+    if (c->is64) HIP_TRY(c, launch_blind_rotate64(c->P, dd, n, instances, slot_stride, static_cast<u64*>(d_acc), c->stream, d_lweN, d_ks, &tail_fused, le0));
+    else HIP_TRY(c, launch_blind_rotate(c->P, dd, n, instances, slot_stride, static_cast<u32*>(d_acc), c->stream, &kid, d_lweN, d_ks, &tail_fused, le0));
     if (events) {
-        hipEventRecord(e0.b, c->stream);
         e0.kind = kid;
         c->pending.push_back(e0);
     }
@@ -565,9 +566,10 @@ int launch_bootstraps(bce_ctx* c, const bce_gate_desc* dd, u32 n, u32 instances,
     }
     if (!tail_fused) {
         EventPair e1{};
+        LaunchEvents le1{};
         if (events) {
             e1 = get_events(c, BCE_BR_KERNELS);  // kind >= BCE_BR_KERNELS: tail
-            hipEventRecord(e1.a, c->stream);
+            le1 = LaunchEvents{e1.a, e1.b};
         }
         if (!d_partial) {
             const size_t need = tail_partial_words(c->P, (u32)nb);
@@ -580,8 +582,8 @@ int launch_bootstraps(bce_ctx* c, const bce_gate_desc* dd, u32 n, u32 instances,
                 c->tail_cap = cap;
             }
         }
-        HIP_TRY(c, launch_tail(c->P, dd, n, instances, slot_stride, d_acc, d_partial ? d_partial : c->d_tail_partial, d_lweN, d_ks, c->stream));
-        if (events) { hipEventRecord(e1.b, c->stream); c->pending.push_back(e1); }
+        HIP_TRY(c, launch_tail(c->P, dd, n, instances, slot_stride, d_acc, d_partial ? d_partial : c->d_tail_partial, d_lweN, d_ks, c->stream, le1));
+        if (events) c->pending.push_back(e1);
     } else if (timed) {
         c->timing.fused_tail_launches += 1;
     }

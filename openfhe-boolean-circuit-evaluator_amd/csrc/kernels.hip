@@ -1382,7 +1382,7 @@ BrKernel pick_br_dg(u32 dG, bool lazy, int occ, bool ap) {
 }  // namespace
 
 hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
-                               u32* acc_out, hipStream_t s, int* kernel_id, u32* dbg_lweN, u32* dbg_ks, bool* tail_fused) {
+                               u32* acc_out, hipStream_t s, int* kernel_id, u32* dbg_lweN, u32* dbg_ks, bool* tail_fused, LaunchEvents ev) {
     if (kernel_id) *kernel_id = BCE_BR_WAVE_PER_TRANSFORM;
     if (tail_fused) *tail_fused = false;
     const u32 R = 2 * P.dG;
@@ -1413,6 +1413,7 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n
         if (tail_fused) *tail_fused = fuse;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lat);
         if (e != hipSuccess) return e;
+        if (ev.start || ev.stop) return launch_with_events(lk, grid, block, lds_lat, s, ev, P, d, n_desc, slot_stride, acc_out, fuse ? dbg_lweN : nullptr, fuse ? dbg_ks : nullptr);
         hipLaunchKernelGGL(lk, grid, block, lds_lat, s, P, d, n_desc, slot_stride, acc_out, fuse ? dbg_lweN : nullptr, fuse ? dbg_ks : nullptr);
         return hipGetLastError();
     }
@@ -1425,6 +1426,7 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n
     if (!kern) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    if (ev.start || ev.stop) return launch_with_events(kern, grid, block, lds, s, ev, P, d, n_desc, slot_stride, acc_out);
     hipLaunchKernelGGL(kern, grid, block, lds, s, P, d, n_desc, slot_stride, acc_out);
     return hipGetLastError();
 }
@@ -1585,25 +1587,33 @@ u32 tail_split(const DevParams& P, u32 boots) {
 size_t tail_partial_words(const DevParams& P, u32 boots) { return (size_t)boots * tail_split(P, boots) * (P.n + 1); }
 
 hipError_t launch_tail(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
-                       const void* acc_in, u64* partial, u32* dbg_lweN, u32* dbg_ks, hipStream_t s) {
+                       const void* acc_in, u64* partial, u32* dbg_lweN, u32* dbg_ks, hipStream_t s, LaunchEvents ev) {
     const u32 boots = n_desc * instances, S = tail_split(P, boots);
     const dim3 grid(boots * S), block(256);
     const u32 VW = P.ksk_u16 ? 8 : 4, G = (P.n + VW) / VW, Gv = G < 256 ? G : 256, RW = (Gv + 63) / 64, SL = 4 / RW;
     const size_t LR = (size_t)P.N / S * P.dKS;
     const size_t red_words = std::max<size_t>((size_t)SL * Gv * VW, 256);
     const size_t lds = ((LR + 3) & ~(size_t)3) * sizeof(u32) + red_words * sizeof(u64);
+    const LaunchEvents first{ev.start, nullptr}, last{nullptr, ev.stop};
+    // the gather carries the start timestamp, the finish the stop (plain launches when none was asked for)
+    auto go = [&](auto kern, dim3 g, size_t l, LaunchEvents e, auto... args) -> hipError_t {
+        if (e.start || e.stop) return launch_with_events(kern, g, block, l, s, e, args...);
+        hipLaunchKernelGGL(kern, g, block, l, s, args...);
+        return hipGetLastError();
+    };
+    hipError_t rc;
     if (P.is64) {
         const u64* a = static_cast<const u64*>(acc_in);
-        if (P.ksk_u16) hipLaunchKernelGGL((k_tail_gather<uint16_t, u64>), grid, block, lds, s, P, S, a, partial, dbg_lweN);
-        else hipLaunchKernelGGL((k_tail_gather<u32, u64>), grid, block, lds, s, P, S, a, partial, dbg_lweN);
-        hipLaunchKernelGGL((k_tail_finish<u64>), dim3(boots), block, 0, s, P, d, n_desc, slot_stride, S, a, partial, dbg_lweN, dbg_ks);
-    } else {
-        const u32* a = static_cast<const u32*>(acc_in);
-        if (P.ksk_u16) hipLaunchKernelGGL((k_tail_gather<uint16_t, u32>), grid, block, lds, s, P, S, a, partial, dbg_lweN);
-        else hipLaunchKernelGGL((k_tail_gather<u32, u32>), grid, block, lds, s, P, S, a, partial, dbg_lweN);
-        hipLaunchKernelGGL((k_tail_finish<u32>), dim3(boots), block, 0, s, P, d, n_desc, slot_stride, S, a, partial, dbg_lweN, dbg_ks);
+        if (P.ksk_u16) rc = go(k_tail_gather<uint16_t, u64>, grid, lds, first, P, S, a, partial, dbg_lweN);
+        else rc = go(k_tail_gather<u32, u64>, grid, lds, first, P, S, a, partial, dbg_lweN);
+        if (rc != hipSuccess) return rc;
+        return go(k_tail_finish<u64>, dim3(boots), 0, last, P, d, n_desc, slot_stride, S, a, partial, dbg_lweN, dbg_ks);
     }
-    return hipGetLastError();
+    const u32* a = static_cast<const u32*>(acc_in);
+    if (P.ksk_u16) rc = go(k_tail_gather<uint16_t, u32>, grid, lds, first, P, S, a, partial, dbg_lweN);
+    else rc = go(k_tail_gather<u32, u32>, grid, lds, first, P, S, a, partial, dbg_lweN);
+    if (rc != hipSuccess) return rc;
+    return go(k_tail_finish<u32>, dim3(boots), 0, last, P, d, n_desc, slot_stride, S, a, partial, dbg_lweN, dbg_ks);
 }
 
 // ---------------------------------------------------------------------------------------

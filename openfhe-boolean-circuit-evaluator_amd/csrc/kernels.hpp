@@ -1,6 +1,9 @@
 // kernels.hpp -- launch interface of the gfx950 kernels (kernels.hip).
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <hip/hip_ext.h>
+
+#include <tuple>
 
 #include <cstdint>
 
@@ -121,6 +124,23 @@ bool dag_kernel_available(const DevParams& P);
 bool dag64_kernel_available(const DevParams& P);
 hipError_t launch_bootstrap_dag64(const DevParams& P, const DevParams* d_P, const DagParams* d_params, u32 grid, hipStream_t s);
 
+// Timestamps of a launch without event packets of their own in the queue: start / stop are attached to the kernel's
+// dispatch (hipExtLaunchKernel) -- what hipEventRecord before and after a kernel costs on the device timeline (5-10 us of
+// idle time each side) is what a dependent step of one bootstrap latency cannot afford.  Null members: nothing attached.
+struct LaunchEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+// kern(args...) with the events attached (or a plain launch when both are null); args are converted to the kernel's own
+// parameter types first
+template <typename... KA, typename... A>
+inline hipError_t launch_with_events(void (*kern)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t s, LaunchEvents ev, A... args) {
+    static_assert(sizeof...(KA) == sizeof...(A), "argument count");
+    std::tuple<KA...> held{static_cast<KA>(args)...};
+    void* ptrs[sizeof...(KA)];
+    std::apply([&](auto&... a) { size_t i = 0; ((ptrs[i++] = (void*)&a), ...); }, held);
+    return hipExtLaunchKernel(reinterpret_cast<const void*>(kern), grid, block, ptrs, lds, s, ev.start, ev.stop, 0);
+}
+
 // acc_out: u32 [n_boot][2][N], COEFFICIENT domain, values in [0, Q)
 // *kernel_id (optional) receives the enum bce_br_kernel value of the kernel that was launched
 // *tail_fused (optional) is set when the launched kernel also ran the tail of EvalBinGate (extract, ModSwitch,
@@ -128,7 +148,7 @@ hipError_t launch_bootstrap_dag64(const DevParams& P, const DevParams* d_P, cons
 // for launch_tail (used only when the tail is fused).
 hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances,
                                u32 slot_stride, u32* acc_out, hipStream_t s, int* kernel_id = nullptr,
-                               u32* dbg_lweN = nullptr, u32* dbg_ks = nullptr, bool* tail_fused = nullptr);
+                               u32* dbg_lweN = nullptr, u32* dbg_ks = nullptr, bool* tail_fused = nullptr, LaunchEvents ev = {});
 
 // extract + ModSwitch(Q->qKS) + KeySwitch + ModSwitch(qKS->q) -> pool[out]
 // dbg_lweN: u32 [n_boot][N+1] or null; dbg_ks: u32 [n_boot][n+1] or null
@@ -136,7 +156,7 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d_descs,
 size_t tail_partial_words(const DevParams& P, u32 boots);
 hipError_t launch_tail(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances, u32 slot_stride,
                        const void* acc_in /* u32 or u64 words by P.is64 */, u64* partial, u32* dbg_lweN, u32* dbg_ks,
-                       hipStream_t s);
+                       hipStream_t s, LaunchEvents ev = {});   // ev.start on the first kernel, ev.stop on the last
 
 // 64-bit-modulus counterparts (kernels64.hip)
 size_t blind_rotate64_lds_bytes(const DevParams& P);
@@ -144,7 +164,7 @@ bool blind_rotate64_narrow(const DevParams& P);   // integer 64-bit kernel with 
 // *tail_fused (optional) is set when the launched kernel also ran the tail (then dbg_lweN / dbg_ks are its debug outputs)
 hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d_descs, u32 n_desc, u32 instances,
                                  u32 slot_stride, u64* acc_out, hipStream_t s, u32* dbg_lweN = nullptr, u32* dbg_ks = nullptr,
-                                 bool* tail_fused = nullptr);
+                                 bool* tail_fused = nullptr, LaunchEvents ev = {});
 hipError_t launch_ntt_batch64(const DevParams& P, u64* polys, u32 count, int inverse, hipStream_t s);
 // key words u64 <-> IEEE double in place (layout of the double-precision formulation)
 hipError_t launch_words_u64_f64(u64* words, size_t count, int to_double, hipStream_t s);

@@ -1422,7 +1422,7 @@ hipError_t launch_bootstrap_dag64(const DevParams& P, const DevParams* d_P, cons
 }
 
 hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32 n_desc, u32 instances, u32 slot_stride,
-                                 u64* acc_out, hipStream_t s, u32* dbg_lweN, u32* dbg_ks, bool* tail_fused) {
+                                 u64* acc_out, hipStream_t s, u32* dbg_lweN, u32* dbg_ks, bool* tail_fused, LaunchEvents ev) {
     using K = void (*)(DevParams, const bce_gate_desc*, u32, u32, u64*, u32*, u32*);
     if (tail_fused) *tail_fused = false;
     const bool ap = P.method_ap != 0;
@@ -1473,6 +1473,9 @@ hipError_t launch_blind_rotate64(const DevParams& P, const bce_gate_desc* d, u32
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const bool fused = tail_fused && *tail_fused;
+    if (ev.start || ev.stop)
+        return launch_with_events(kern, dim3(n_desc * instances), dim3(threads), lds, s, ev, P, d, n_desc, slot_stride, acc_out,
+                                  fused ? dbg_lweN : nullptr, fused ? dbg_ks : nullptr);
     hipLaunchKernelGGL(kern, dim3(n_desc * instances), dim3(threads), lds, s, P, d, n_desc, slot_stride, acc_out,
                        fused ? dbg_lweN : nullptr, fused ? dbg_ks : nullptr);
     return hipGetLastError();
