@@ -273,6 +273,14 @@ int bce_rccl_shutdown(bce_ctx*);
  * u64 [n_desc][N+1]; ks = after KeySwitch, u64 [n_desc][n+1].  Bootstrapped ops only. */
 int bce_debug_eval_stages(bce_ctx*, uint32_t n_desc, const bce_gate_desc* descs, uint64_t* acc,
                           uint64_t* lweN, uint64_t* ks);
+/* The tail of EvalBinGate alone on caller-supplied accumulators: acc = u64 [count][2][N], COEFFICIENT domain, words < Q
+ * (what `acc` of bce_debug_eval_stages returns).  Runs transpose + extract (a = coefficients of acc[0](X^-1),
+ * b = acc[1][0] + Q/8 + 1), ModSwitch(Q -> qKS), KeySwitch, ModSwitch(qKS -> q) -- lbcrypto::LWEEncryptionScheme::
+ * ModSwitch / KeySwitch as BinFHEScheme::EvalBinGate calls them after the accumulator -- and writes the refreshed
+ * ciphertexts to pool slots out_slots[count]; lweN / ks (may be NULL) as in bce_debug_eval_stages.  Used by
+ * tools/openfhe_export/compare.py to replay OpenFHE's own tail records (kind BCE_GATEVEC_TAIL of bce_keyfile.h). */
+int bce_debug_tail(bce_ctx*, uint32_t count, const uint64_t* acc, const uint32_t* out_slots, uint64_t* lweN,
+                   uint64_t* ks);
 /* forward (inverse=0) / inverse negacyclic NTT of `count` polys, in place, u64 [count][N];
  * forward output is in the engine's internal evaluation order. */
 int bce_debug_ntt(bce_ctx*, uint64_t* polys, uint32_t count, int inverse);

@@ -61,7 +61,7 @@ ENGINE_SYMBOLS = [
     "bce_export_ksk", "bce_pool_reserve", "bce_pool_slots", "bce_lwe_write", "bce_lwe_read",
     "bce_encrypt_bits", "bce_set_encrypt_seed", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize",
     "bce_timing_reset", "bce_timing_get", "bce_timing_set_events", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_forward_transforms_per_step", "bce_launch_capacity", "bce_rccl_available", "bce_rccl_version", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
-    "bce_rccl_shutdown", "bce_debug_eval_stages", "bce_debug_ntt",
+    "bce_rccl_shutdown", "bce_debug_eval_stages", "bce_debug_ntt", "bce_debug_tail",
     "bce_dag_supported", "bce_dag_create", "bce_dag_run", "bce_dag_destroy", "bce_dag_set_limits", "bce_dag_last_run", "bce_dag_debug_block_task",
     "bce_plan_create", "bce_plan_run_step", "bce_plan_run", "bce_plan_destroy",
 ]
@@ -130,6 +130,7 @@ def lib():
     L.bce_rccl_shutdown.argtypes = [vp]
     L.bce_debug_eval_stages.argtypes = [vp, u32, vp, vp, vp, vp]
     L.bce_debug_ntt.argtypes = [vp, vp, u32, i32]
+    L.bce_debug_tail.argtypes = [vp, u32, vp, vp, vp, vp]
     L.bce_dag_supported.argtypes = [vp]
     L.bce_dag_create.argtypes = [vp, u32, vp, vp, C.POINTER(vp)]
     L.bce_dag_run.argtypes = [vp, vp, u32, u32, u32]
@@ -436,6 +437,17 @@ class BinFHEContext:
         ks = np.zeros((nb, self.n + 1), dtype=np.uint64)
         self._ck(self._L.bce_debug_eval_stages(self.h, nb, arr, _p(acc), _p(lweN), _p(ks)))
         return acc, lweN, ks
+
+    def debug_tail(self, acc, out_slots):
+        """the tail of EvalBinGate alone on caller-supplied coefficient-form accumulators [count][2][N];
+        refreshed ciphertexts go to out_slots; returns (lweN mod qKS, ks mod qKS)"""
+        acc = np.ascontiguousarray(acc, dtype=np.uint64).reshape(-1, 2 * self.N)
+        slots = np.ascontiguousarray(out_slots, dtype=np.uint32)
+        assert slots.size == acc.shape[0]
+        lweN = np.zeros((slots.size, self.N + 1), dtype=np.uint64)
+        ks = np.zeros((slots.size, self.n + 1), dtype=np.uint64)
+        self._ck(self._L.bce_debug_tail(self.h, slots.size, _p(acc), _p(slots), _p(lweN), _p(ks)))
+        return lweN, ks
 
     def debug_ntt(self, polys, inverse=False):
         polys = np.array(polys, dtype=np.uint64, order="C")

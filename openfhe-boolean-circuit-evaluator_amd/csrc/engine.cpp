@@ -1484,6 +1484,56 @@ int bce_debug_eval_stages(bce_ctx* c, uint32_t n_desc, const bce_gate_desc* desc
     return eval_impl(c, n_desc, descs, 1, 0, acc, lweN, ks);
 }
 
+// The tail of EvalBinGate alone (transpose + extract, ModSwitch Q -> qKS, KeySwitch, ModSwitch qKS -> q) on accumulators
+// the CALLER supplies: what tools/openfhe_export/compare.py replays OpenFHE's LWEEncryptionScheme::ModSwitch / KeySwitch
+// records on, so that a mismatch in a gate vector can be told apart from one in the tail.  Runs the separate tail kernels.
+int bce_debug_tail(bce_ctx* c, uint32_t count, const uint64_t* acc, const uint32_t* out_slots, uint64_t* lweN, uint64_t* ks) {
+    if (!c || !acc || !out_slots) return BCE_ERR_ARG;
+    if (count == 0) return BCE_OK;
+    if (!c->have_keys) return c->fail(BCE_ERR_NO_KEYS, "bce_keygen / bce_import_keys has not been called");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t words = (size_t)count * 2 * c->N;
+    for (size_t i = 0; i < words; ++i)
+        if (acc[i] >= c->Q) return c->fail(BCE_ERR_ARG, "accumulator word not reduced mod Q");
+    std::vector<bce_gate_desc> d(count);
+    for (u32 i = 0; i < count; ++i) {
+        if (out_slots[i] >= c->pool_slots) return c->fail(BCE_ERR_POOL, "slot %u outside the pool", out_slots[i]);
+        d[i] = bce_gate_desc{BCE_AND, out_slots[i], out_slots[i], out_slots[i], 0, 0};
+    }
+    void* d_in = nullptr;
+    u32 *d_lweN = nullptr, *d_ks = nullptr;
+    u64* d_partial = nullptr;
+    HIP_TRY(c, hipMalloc(&d_in, words * c->wbytes));
+    HIP_TRY(c, hipMalloc(&d_lweN, (size_t)count * (c->N + 1) * sizeof(u32)));
+    HIP_TRY(c, hipMalloc(&d_ks, (size_t)count * (c->n + 1) * sizeof(u32)));
+    HIP_TRY(c, hipMalloc(&d_partial, std::max<size_t>(1, tail_partial_words(c->P, count)) * sizeof(u64)));
+    std::vector<u32> tmp;
+    if (c->is64) {
+        HIP_TRY(c, hipMemcpy(d_in, acc, words * 8, hipMemcpyHostToDevice));
+    } else {
+        tmp.assign(acc, acc + words);
+        HIP_TRY(c, hipMemcpy(d_in, tmp.data(), words * 4, hipMemcpyHostToDevice));
+    }
+    bce_gate_desc* dd = nullptr;
+    int slot = 0;
+    int rc = stage_descs(c, d.data(), count, &dd, &slot);
+    if (rc) return rc;
+    HIP_TRY(c, launch_tail(c->P, dd, count, 1, 0, d_in, d_partial, d_lweN, d_ks, c->stream, LaunchEvents{}));
+    hipEventRecord(c->ring_ev[slot], c->stream);
+    c->ring_busy[slot] = true;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    auto fetch = [&](const u32* dev, size_t n, u64* dst) -> int {
+        tmp.resize(n);
+        HIP_TRY(c, hipMemcpy(tmp.data(), dev, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) dst[i] = tmp[i];
+        return BCE_OK;
+    };
+    if (lweN && (rc = fetch(d_lweN, (size_t)count * (c->N + 1), lweN))) return rc;
+    if (ks && (rc = fetch(d_ks, (size_t)count * (c->n + 1), ks))) return rc;
+    hipFree(d_in); hipFree(d_lweN); hipFree(d_ks); hipFree(d_partial);
+    return BCE_OK;
+}
+
 static int pool_pack(bce_ctx* c, const uint32_t* slots, uint32_t count, void* dev, int to_pool) {
     if (!c || !slots || !dev) return BCE_ERR_ARG;
     if (count == 0) return BCE_OK;

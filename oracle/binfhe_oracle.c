@@ -6,8 +6,9 @@
  * src/gate.cpp:112,133,146,172,198-202).  OpenFHE is a third-party dependency
  * that is absent from /root/reference and from this image; upstream file names
  * are cited per function ("upstream:") from the published v1.0.x sources.
- * PARITY UNPINNED at ciphertext level (no golden ciphertexts exist anywhere in
- * the reference); pinned by functional KATs only.
+ * Pinned to the reference's functional known answers by the oracle-alone walks
+ * of tests/test_oracle.py (see the header); PARITY UNPINNED at ciphertext level
+ * (no golden ciphertexts exist anywhere in the reference).
  *
  * Word layout follows the reference: every ring / LWE element is a uint64_t
  * (OpenFHE NativeInteger).  Internal NTT ordering follows OpenFHE (forward =

@@ -14,12 +14,21 @@
  * of that release (file names given per function) and parity is anchored on
  * the reference's own call sites and functional known-answer tests.
  *
- * PARITY UNPINNED at ciphertext level: the reference holds no golden
- * ciphertext / key vector for this path and OpenFHE cannot be built here, so
- * this oracle is pinned only by (a) gate truth tables after decryption,
- * (b) the reference harnesses' functional KATs (adders, comparators,
- * multiplier, parity, md5, sha-256, AES) and (c) algebraic self checks
- * (NTT vs schoolbook negacyclic product, noise bounds).
+ * PINNED to every known answer the reference holds for this path: the oracle
+ * ALONE (tests/oracle_walk.py: its own netlist readers, SetInput / Clock /
+ * Gate::Evaluate restated on the calls below, no product code) evaluates
+ * adder_2bit.out on all 16 inputs, parity.out, adder_32bit and two comparators
+ * on the harnesses' srand() vectors and AES-expanded on the first vector of
+ * src/test_aes.cpp:186-228 (66,415 gate bootstraps, XOR = NOT, NOT, AND, AND,
+ * OR) and decrypts the reference's golden outputs (tests/test_oracle.py,
+ * test_oracle_alone_*).  Further: gate truth tables, NTT vs schoolbook
+ * negacyclic product, the blind rotation against an NTT-free restatement,
+ * noise bounds.
+ * PARITY UNPINNED at CIPHERTEXT level: the reference holds no golden
+ * ciphertext / key vector (keys and noise come from OpenFHE's unseeded PRNG,
+ * src/circuit.cpp:88-91) and OpenFHE cannot be built here.  The kit that
+ * closes this on a machine with OpenFHE is tools/openfhe_export/
+ * (export_keys.cpp records OpenFHE's own outputs, compare.py replays them).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product (libbce_amd.so) never links or calls it.

@@ -3,7 +3,8 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
 module.  It wraps oracle/_build/libbinfhe_oracle.so (built by oracle/Makefile), the plain-C
 restatement of the OpenFHE binfhe path the reference calls at src/gate.cpp:112,133,172,
-198-202 and src/circuit.cpp:88-91,506,800.  PARITY UNPINNED at ciphertext level
+198-202 and src/circuit.cpp:88-91,506,800.  Pinned to the reference's functional known answers
+(tests/test_oracle.py::test_oracle_alone_*); PARITY UNPINNED at ciphertext level against OpenFHE
 (see binfhe_oracle.h).
 """
 import ctypes as C

@@ -282,3 +282,75 @@ def test_blind_rotation_equals_its_coefficient_domain_definition(orc, method):
                     acc = prods[0]
         assert np.array_equal(acc.astype(np.uint64), o.blind_rotate(gate, prep).reshape(2, N)), "gate %d" % gate
     o.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The oracle ALONE on the reference's own known answers.  tests/oracle_walk.py restates SetInput /
+# Clock / Gate::Evaluate on oracle calls (no product code: its own netlist readers, the oracle's batched entry point);
+# the inputs and goldens are those of the reference harnesses (tests/kat.py cites them).
+# ---------------------------------------------------------------------------------------------------------------------
+import kat
+import oracle_walk as W
+
+
+@pytest.fixture(scope="module")
+def toy(orc):
+    o = orc.Oracle(orc.TOY, orc.GINX)
+    o.keygen(0xC0FFEE)
+    yield o
+    o.close()
+
+
+def test_oracle_alone_adder_2bit_all_sixteen_inputs(orc, toy):
+    """examples/simple_ckts/adder_2bit/adder_2bit.out (hand-written, holds the only OR gate of the tree)."""
+    nl = W.read_assembler_text(os.path.join(kat.CIRCUITS, "adder_2bit.out"))
+    assert [g[0] for g in nl.gates].count("OR") == 1 and len(nl.loads) == 4 and len(nl.stores) == 3
+    idx = 0
+    for a in range(4):
+        for b in range(4):
+            out, boots = W.evaluate(orc, toy, nl, [[a & 1, a >> 1], [b & 1, b >> 1]], enc_index=idx)
+            idx += 4
+            assert kat.to_int(out) == a + b, (a, b, out)
+            assert boots == 13 + 4                      # SURVEY App. C: 13 gate bootstraps (+ one refresh per input bit)
+
+
+def test_oracle_alone_parity_harness_vectors(orc, toy):
+    """src/test_parity.cpp:176-206: srand(test_ix) inputs, outputs (even, odd)."""
+    nl = W.read_assembler_text(os.path.join(kat.CIRCUITS, "parity.out"))
+    for test_ix in range(4):
+        ins, want = kat.parity_case(test_ix)
+        out, _ = W.evaluate(orc, toy, nl, ins, enc_index=1000 + 16 * test_ix)
+        assert out == want, test_ix
+
+
+def test_oracle_alone_adder_32bit_harness_vectors(orc, toy):
+    """src/test_adder.cpp:180-217 on examples/old_bristol_ckts/arith/adder_32bit.txt (310 bootstraps, 127 rounds)."""
+    nl = W.read_bristol_old(os.path.join(kat.CIRCUITS, "adder_32bit.txt"))
+    assert len(nl.gates) == 375
+    for test_ix in (0, 1):
+        ins, want = kat.adder_case(test_ix, 32)
+        out, boots = W.evaluate(orc, toy, nl, ins, enc_index=2000 + 64 * test_ix)
+        assert out == want, test_ix
+        assert boots == 310 + 64
+
+
+@pytest.mark.parametrize("fname", ["comparator_32bit_signed_lt.txt", "comparator_32bit_unsigned_lteq.txt"])
+def test_oracle_alone_comparator_harness_vectors(orc, toy, fname):
+    """src/test_comparator.cpp:184-269 (test_ix 0 compares a value with itself)."""
+    nl = W.read_bristol_old(os.path.join(kat.CIRCUITS, fname))
+    for test_ix in (0, 1, 2):
+        ins, want = kat.comparator_case(test_ix, fname)
+        out, _ = W.evaluate(orc, toy, nl, ins, enc_index=3000 + 64 * test_ix)
+        assert out == want, (fname, test_ix)
+
+
+def test_oracle_alone_aes_expanded_vector_0(orc, toy):
+    """src/test_aes.cpp:186-228, first vector, on examples/old_bristol_ckts/crypto/AES-expanded.txt at TOY
+    parameters: 27,692 gates, 66,415 gate bootstraps (XOR = NOT, NOT, AND, AND, OR) + 1,536 input refreshes, every one
+    on the oracle; the 128 decrypted output bits must be the reference's golden string."""
+    nl = W.read_bristol_old(os.path.join(kat.CIRCUITS, "AES-expanded.txt"))
+    assert len(nl.gates) == 27692 and len(W.rounds(nl)) == 248      # SURVEY App. C
+    ins, want = kat.aes_case(kat.AES_VECTORS[0])
+    out, boots = W.evaluate(orc, toy, nl, ins, enc_index=10000)
+    assert boots == 66415 + 1536
+    assert out == want

@@ -50,4 +50,65 @@ typedef struct bce_keyfile_header {
 } bce_keyfile_header; /* 104 bytes */
 #pragma pack(pop)
 
+
+/*
+ * ---- gate-vector file ("BCEGVEC1") --------------------------------------------------------------------------------
+ * What OpenFHE itself RETURNED for the calls the reference makes on BinFHEContext (EvalBinGate src/gate.cpp:133,146,172,
+ * 200-202; EvalNOT :112,198-199; Encrypt src/circuit.cpp:506; Decrypt :800), recorded by export_keys.cpp next to the
+ * keys of the same context and replayed on the engine by tools/openfhe_export/compare.py: every output word must be
+ * identical.  This file is the ciphertext-level parity statement against the reference's own encrypted path.
+ *
+ *   offset  size  field
+ *   0       8     magic "BCEGVEC1"
+ *   8       4     version (1)
+ *   12      4     method (1 AP, 2 GINX)
+ *   16      8x8   n, N, q, Q, qKS, baseKS, baseG, baseR      must equal the key file's
+ *   80      8     count                                      number of records that follow
+ *   88            records, back to back
+ *
+ * record:
+ *   0       4     kind            (enum below)
+ *   4       4     in_bits         bit 0 / bit 1: the plaintexts behind ct1 / ct2 (documentation; Encrypt: the bit)
+ *   8       4     decrypted       what OpenFHE's Decrypt(sk, out) returned (TAIL, NTT records: 0)
+ *   12      4     payload_words   u64 words that follow
+ *   16      8*payload_words       payload, u64 words:
+ *
+ *   kind 0..5   EvalBinGate(gate = kind: OR, AND, NOR, NAND, XOR_FAST, XNOR_FAST -- lbcrypto::BINGATE order)
+ *               ct1[n+1], ct2[n+1], out[n+1]           every ciphertext as (a_0 .. a_{n-1}, b) mod q
+ *   kind 16     EvalNOT(ct1):                          ct1[n+1], out[n+1]
+ *   kind 17     Bootstrap(ct1):                        ct1[n+1], out[n+1]
+ *   kind 32     Encrypt(sk, bit) in the library's DEFAULT output mode: out[n+1]   (not replayable: checked for its
+ *               plaintext and its noise, which tells FRESH from BOOTSTRAPPED defaults apart)
+ *   kind 33     Encrypt(sk, bit, FRESH):               out[n+1]
+ *   kind 48     TAIL -- the calls EvalBinGate makes after the accumulator, through the public LWE scheme:
+ *               ctQ[N+1] (an LWE ciphertext of dimension N mod Q), lweN[N+1] = ModSwitch(qKS, ctQ),
+ *               ks[n+1] = KeySwitch(params, K, lweN), out[n+1] = ModSwitch(q, ks).  Localises a gate mismatch:
+ *               tail records equal + gate records different => the difference is in the blind rotation.
+ *   kind 64     NTT -- coef[N], eval[N] = the same NativePoly after SetFormat(EVALUATION): pins the evaluation order
+ *               bsk_format = 1 key files rely on (bce_debug_ntt of coef must equal eval).
+ */
+#define BCE_GATEVEC_MAGIC "BCEGVEC1"
+#define BCE_GATEVEC_VERSION 1u
+enum {
+    BCE_GATEVEC_OR = 0, BCE_GATEVEC_AND = 1, BCE_GATEVEC_NOR = 2, BCE_GATEVEC_NAND = 3, BCE_GATEVEC_XOR_FAST = 4,
+    BCE_GATEVEC_XNOR_FAST = 5, BCE_GATEVEC_NOT = 16, BCE_GATEVEC_BOOTSTRAP = 17, BCE_GATEVEC_ENCRYPT_DEFAULT = 32,
+    BCE_GATEVEC_ENCRYPT_FRESH = 33, BCE_GATEVEC_TAIL = 48, BCE_GATEVEC_NTT = 64
+};
+
+#pragma pack(push, 1)
+typedef struct bce_gatevec_header {
+    char     magic[8];
+    uint32_t version;
+    uint32_t method;
+    uint64_t n, N, q, Q, qKS, baseKS, baseG, baseR;
+    uint64_t count;
+} bce_gatevec_header; /* 88 bytes */
+typedef struct bce_gatevec_record {
+    uint32_t kind;
+    uint32_t in_bits;
+    uint32_t decrypted;
+    uint32_t payload_words;
+} bce_gatevec_record; /* 16 bytes, followed by payload_words u64 words */
+#pragma pack(pop)
+
 #endif

@@ -21,16 +21,24 @@
 // SetFormat pass over the key) and marks the file bsk_format = 1; the engine imports that without a transform
 // (bce_import_keys_eval): the engine's evaluation order is OpenFHE's (bit-reversed CT order, minimal primitive 2N-th root).
 // usage:
-//   export_keys <TOY|STD128_OPT|...> <AP|GINX> <keys.bce> [<ciphertexts.bin> <bit> ...]
-//     generates a context + keys exactly like the reference's Circuit constructor, writes the keys, and
+//   export_keys <TOY|STD128_OPT|...> <AP|GINX> <keys.bce> [--vectors <vectors.bgv> <M>] [<ciphertexts.bin> <bit> ...]
+//     generates a context + keys exactly like the reference's Circuit constructor and writes the keys;
+//     --vectors: also records what OpenFHE RETURNS for M (e.g. 64) random EvalBinGate calls over all six gates (inputs
+//       are fresh encryptions and earlier gate outputs), EvalNOT, Bootstrap, Encrypt in the default and the FRESH mode,
+//       Decrypt of every result, plus tail and NTT probes, in the "BCEGVEC1" format of bce_keyfile.h.  Then, on a machine
+//       with an MI355X:  python tools/openfhe_export/compare.py keys.bce vectors.bgv   (exit code 0 = every word equal);
 //     optionally encrypts the given bits and appends them as u64[n+1] words each (a_0..a_{n-1}, b) mod q,
 //     the layout bce_lwe_write() takes.
+// The probes use LWEEncryptionScheme::ModSwitch(q, ct) / KeySwitch(params, K, ct) and NativePoly::SetFormat as of v1.0.x;
+// build with -DBCE_EXPORT_NO_PROBES if the installed release spells them differently (the gate records do not need them).
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -62,12 +70,120 @@ void put_rgsw(FILE* f, const RingGSWEvalKey& ek, uint32_t N) {
         }
 }
 
+std::vector<uint64_t> words_of(ConstLWECiphertext ct) {
+    const uint32_t n = ct->GetA().GetLength();
+    std::vector<uint64_t> w(n + 1);
+    for (uint32_t k = 0; k < n; ++k) w[k] = ct->GetA()[k].ConvertToInt();
+    w[n] = ct->GetB().ConvertToInt();
+    return w;
+}
+
+struct VectorFile {
+    FILE* f = nullptr;
+    uint64_t count = 0;
+    void open(const char* path, const bce_keyfile_header& k) {
+        f = std::fopen(path, "wb");
+        if (!f) throw std::runtime_error("cannot open the vector file for writing");
+        bce_gatevec_header h{};
+        std::memcpy(h.magic, BCE_GATEVEC_MAGIC, 8);
+        h.version = BCE_GATEVEC_VERSION;
+        h.method = k.method;
+        h.n = k.n; h.N = k.N; h.q = k.q; h.Q = k.Q; h.qKS = k.qKS; h.baseKS = k.baseKS; h.baseG = k.baseG; h.baseR = k.baseR;
+        h.count = 0;  // patched by close()
+        put(f, &h, sizeof h);
+    }
+    void record(uint32_t kind, uint32_t in_bits, uint32_t decrypted, const std::vector<const std::vector<uint64_t>*>& parts) {
+        bce_gatevec_record r{kind, in_bits, decrypted, 0};
+        for (const auto* p : parts) r.payload_words += (uint32_t)p->size();
+        put(f, &r, sizeof r);
+        for (const auto* p : parts) put(f, p->data(), p->size() * sizeof(uint64_t));
+        ++count;
+    }
+    void close() {
+        std::fseek(f, offsetof(bce_gatevec_header, count), SEEK_SET);
+        put(f, &count, sizeof count);
+        std::fclose(f);
+        f = nullptr;
+    }
+};
+
+// What OpenFHE returns for the calls the reference makes (src/gate.cpp:112,133,146,172,198-202; src/circuit.cpp:506,800)
+void write_vectors(BinFHEContext& cc, LWEPrivateKey sk, const bce_keyfile_header& kh, const char* path, uint32_t M) {
+    VectorFile vf;
+    vf.open(path, kh);
+    std::mt19937_64 rng(0xB0017E57ull);   // chooses gates, operands and bits only; all ciphertext randomness is OpenFHE's
+    struct Operand { LWECiphertext ct; uint32_t bit; };
+    std::vector<Operand> live;
+    auto decrypt = [&](ConstLWECiphertext ct) { LWEPlaintext r = 0; cc.Decrypt(sk, ct, &r); return (uint32_t)r; };
+
+    for (uint32_t i = 0; i < 8; ++i) {    // fresh inputs; and what cc.Encrypt(sk, bit) -- the call at src/circuit.cpp:506 -- returns
+        const uint32_t bit = (uint32_t)(rng() & 1);
+        LWECiphertext fresh = cc.Encrypt(sk, bit, FRESH);
+        const auto wf = words_of(fresh);
+        vf.record(BCE_GATEVEC_ENCRYPT_FRESH, bit, decrypt(fresh), {&wf});
+        live.push_back({fresh, bit});
+        LWECiphertext dflt = cc.Encrypt(sk, bit);
+        const auto wd = words_of(dflt);
+        vf.record(BCE_GATEVEC_ENCRYPT_DEFAULT, bit, decrypt(dflt), {&wd});
+        live.push_back({dflt, bit});
+    }
+    for (uint32_t g = 0; g < M; ++g) {
+        const uint32_t gate = (uint32_t)(rng() % 6);
+        size_t i = rng() % live.size(), j = rng() % live.size();
+        if (i == j) j = (j + 1) % live.size();   // EvalBinGate refuses ct1 == ct2
+        LWECiphertext out = cc.EvalBinGate((BINGATE)gate, live[i].ct, live[j].ct);
+        const auto w1 = words_of(live[i].ct), w2 = words_of(live[j].ct), wo = words_of(out);
+        const uint32_t dec = decrypt(out);
+        vf.record(gate, live[i].bit | (live[j].bit << 1), dec, {&w1, &w2, &wo});
+        live.push_back({out, dec & 1});
+    }
+    for (uint32_t k = 0; k < 6; ++k) {
+        const Operand& a = live[rng() % live.size()];
+        const auto wi = words_of(a.ct);
+        LWECiphertext nt = cc.EvalNOT(a.ct);
+        const auto wn = words_of(nt);
+        vf.record(BCE_GATEVEC_NOT, a.bit, decrypt(nt), {&wi, &wn});
+        LWECiphertext bt = cc.Bootstrap(a.ct);
+        const auto wb = words_of(bt);
+        vf.record(BCE_GATEVEC_BOOTSTRAP, a.bit, decrypt(bt), {&wi, &wb});
+    }
+#ifndef BCE_EXPORT_NO_PROBES
+    {
+        const auto lwe = cc.GetParams()->GetLWEParams();
+        const auto scheme = cc.GetLWEScheme();
+        const uint32_t N = lwe->GetN();
+        const NativeInteger Q = lwe->GetQ();
+        std::uniform_int_distribution<uint64_t> modQ(0, Q.ConvertToInt() - 1);
+        for (uint32_t t = 0; t < 4; ++t) {   // the calls EvalBinGate makes after the accumulator (binfhe-base-scheme.cpp)
+            NativeVector a(N, Q);
+            for (uint32_t k = 0; k < N; ++k) a[k] = NativeInteger(modQ(rng));
+            LWECiphertext ctQ = std::make_shared<LWECiphertextImpl>(std::move(a), NativeInteger(modQ(rng)));
+            LWECiphertext ctKS = scheme->ModSwitch(lwe->GetqKS(), ctQ);
+            LWECiphertext ks = scheme->KeySwitch(lwe, cc.GetSwitchKey(), ctKS);
+            LWECiphertext out = scheme->ModSwitch(lwe->Getq(), ks);
+            const auto w0 = words_of(ctQ), w1 = words_of(ctKS), w2 = words_of(ks), w3 = words_of(out);
+            vf.record(BCE_GATEVEC_TAIL, 0, 0, {&w0, &w1, &w2, &w3});
+        }
+        const auto poly_params = cc.GetParams()->GetRingGSWParams()->GetPolyParams();
+        for (uint32_t t = 0; t < 2; ++t) {   // the evaluation order a bsk_format = 1 key file relies on
+            NativePoly p(poly_params, Format::COEFFICIENT, true);
+            std::vector<uint64_t> coef(N), eval(N);
+            for (uint32_t k = 0; k < N; ++k) { coef[k] = modQ(rng); p[k] = NativeInteger(coef[k]); }
+            p.SetFormat(Format::EVALUATION);
+            for (uint32_t k = 0; k < N; ++k) eval[k] = p[k].ConvertToInt();
+            vf.record(BCE_GATEVEC_NTT, 0, 0, {&coef, &eval});
+        }
+    }
+#endif
+    vf.close();
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
     { const char* e = std::getenv("BCE_EXPORT_EVALUATION"); g_evaluation_form = e && e[0] == '1'; }
     if (argc < 4) {
-        std::fprintf(stderr, "usage: %s <paramset> <AP|GINX> <keys.bce> [<cts.bin> <bit> ...]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <paramset> <AP|GINX> <keys.bce> [--vectors <vectors.bgv> <M>] [<cts.bin> <bit> ...]\n", argv[0]);
         return 2;
     }
     const std::map<std::string, BINFHE_PARAMSET> sets = {
@@ -142,11 +258,16 @@ int main(int argc, char** argv) {
     }
     std::fclose(f);
 
-    if (argc >= 6) {  // ciphertexts for a gate-level comparison: u64[n+1] each
-        FILE* c = std::fopen(argv[4], "wb");
+    int rest = 4;
+    if (argc >= rest + 3 && std::string(argv[rest]) == "--vectors") {
+        write_vectors(cc, sk, h, argv[rest + 1], (uint32_t)std::atoi(argv[rest + 2]));
+        rest += 3;
+    }
+    if (argc >= rest + 2) {  // ciphertexts for a gate-level comparison: u64[n+1] each
+        FILE* c = std::fopen(argv[rest], "wb");
         if (!c) throw std::runtime_error("cannot open the ciphertext file for writing");
         std::vector<uint64_t> words(n + 1);
-        for (int a = 5; a < argc; ++a) {
+        for (int a = rest + 1; a < argc; ++a) {
             const LWECiphertext ct = cc.Encrypt(sk, std::atoi(argv[a]), FRESH);
             for (uint32_t k = 0; k < n; ++k) words[k] = ct->GetA()[k].ConvertToInt();
             words[n] = ct->GetB().ConvertToInt();
