@@ -261,8 +261,7 @@ def main():
         gates = world > 1 and shard_mode == 1
         if gates:
             cc.set_encrypt_seed(0x0FE5EED)   # every rank must encrypt IDENTICAL input ciphertexts
-        if relevel:
-            circ.setRelevel(True)
+        circ.setRelevel(bool(relevel))
         if args.schedule == "dataflow" and not gates:
             circ.setDataflow(True)
         if args.schedule == "graph" and not gates:
@@ -380,8 +379,7 @@ def main():
     def single_block_latency():
         c1 = bce.Circuit(cc)
         c1.ReadBristol(path, new_flag=args.circuit.startswith("sha256_new"))
-        if args.relevel:
-            c1.setRelevel(True)
+        c1.setRelevel(bool(args.relevel))
         c1.Reset()
         c1.setEncrypted(True)
         w = [x for x in c1.info()["n_input_bits"] if x]

@@ -57,7 +57,10 @@ typedef int (*bce_allgather_fn)(void* user, uint64_t bytes, int on_device);
 
 /* Circuit::Circuit(set, method), src/circuit.cpp:45-98, but the engine (keys included) is
  * passed in so that several circuits can share one.  engine == NULL gives a
- * plaintext-only circuit (host logic, no GPU needed); encrypted mode then fails loudly. */
+ * plaintext-only circuit (host logic, no GPU needed); encrypted mode then fails loudly.
+ * Lifetime: a circuit uses its engine until it is destroyed, so destroy circuits first.  The other order is tolerated for
+ * tear-down only: bce_ctx_destroy releases the device-side schedules (bce_plan / bce_dag) the engine's circuits created, and
+ * a circuit destroyed afterwards touches nothing of the engine; any other call on it is an error. */
 int bce_circuit_create(bce_ctx* engine, bce_circuit** out);
 void bce_circuit_destroy(bce_circuit*);
 const char* bce_circuit_last_error(const bce_circuit*);
@@ -91,9 +94,17 @@ int bce_circuit_get_encrypt_mode(const bce_circuit*);
  * (one bootstrap of 2*(ct1-ct2) instead of NOT,NOT,AND,AND,OR); the reference keeps this disabled
  * because of its higher failure rate (src/gate.cpp:194-203) */
 int bce_circuit_set_xor_fast(bce_circuit*, int on);
-/* opt-in extension: schedule by bootstrap depth (NOTs folded into consumers, an XOR's OR launched with
- * the next level's ANDs).  Same ciphertexts, fewer dependent launches; encrypted-only runs, no verify. */
+/* Schedule by bootstrap depth (NOTs folded into consumers, an XOR's OR launched with the next level's ANDs): the
+ * same ciphertext in every bootstrapped register as the reference's gate-level rounds -- asserted register by register on
+ * AES-expanded, tests/test_gpu_circuit.py -- in fewer dependent launches (AES-expanded: 416 instead of 496, one block
+ * 0.82 s instead of 1.02 s).  DEFAULT ON since round 4: a caller that writes the reference's own sequence (Circuit; ReadFile;
+ * Reset; setEncrypted; SetInput; Clock -- src/test_aes.cpp:338-343) gets it with slack-filled steps and the schedule's
+ * descriptors resident on the device.  on = 0 restores the reference's Clock rounds (src/circuit.cpp:532-573: one round per
+ * gate level, NOT gates materialised).  Gate-level rounds also run whenever a plaintext pass rides along (verify mode) or
+ * with bce_circuit_set_batched(0).  Registers of NOT gates hold a ciphertext only under the gate-level rounds (or when an
+ * OUTPUT gate reads them). */
 int bce_circuit_set_relevel(bce_circuit*, int on);
+int bce_circuit_get_relevel(bce_circuit*);
 /* The bootstrap-depth schedule fills its steps BY SLACK up to the launch staircase of the engine (default on): one
  * bootstrap is one workgroup, so a frontier call costs one bootstrap latency up to `lone` bootstraps and one more round
  * per `full` beyond (bce_launch_capacity); a step holding K x count bootstraps is topped up to the next stair with the

@@ -350,7 +350,8 @@ class BinFHEContext:
     def dag_last_run(self):
         out = (C.c_uint64 * 7)()
         self._ck(self._L.bce_dag_last_run(self.h, out))
-        d = {"done": int(out[0]), "lazy_waits": int(out[1]), "abort": int(out[2]), "workgroups_per_cu": int(out[3])}
+        d = {"done": int(out[0]), "lazy_waits": int(out[1]), "abort": int(out[2]), "workgroups_per_cu": int(out[3]),
+             "busy_ticks": int(out[4]), "wait_ticks": int(out[5]), "gate_ticks": int(out[6])}
         if out[0]:
             d["ms_per_bootstrap"] = round(out[4] / out[0] / 1e5, 4)        # 100 MHz ticks
             d["wait_ms_per_bootstrap"] = round(out[5] / out[0] / 1e5, 4)
@@ -479,7 +480,7 @@ CIRCUIT_SYMBOLS = [
     "bce_circuit_create", "bce_circuit_destroy", "bce_circuit_last_error", "bce_circuit_read_file",
     "bce_circuit_read_bristol", "bce_circuit_get_info", "bce_circuit_reset", "bce_circuit_rearm", "bce_circuit_set_plaintext",
     "bce_circuit_set_encrypted", "bce_circuit_set_verify", "bce_circuit_get_flags", "bce_circuit_set_batched",
-    "bce_circuit_set_encrypt_mode", "bce_circuit_get_encrypt_mode", "bce_circuit_plan_hash", "bce_circuit_set_shard_locality", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_set_dataflow", "bce_circuit_dataflow_active", "bce_circuit_set_graph", "bce_circuit_graph_active", "bce_circuit_dataflow_plan", "bce_circuit_set_balance", "bce_circuit_relevel_steps", "bce_circuit_relevel_publications", "bce_circuit_check_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
+    "bce_circuit_set_encrypt_mode", "bce_circuit_get_encrypt_mode", "bce_circuit_plan_hash", "bce_circuit_set_shard_locality", "bce_circuit_set_xor_fast", "bce_circuit_set_relevel", "bce_circuit_get_relevel", "bce_circuit_set_dataflow", "bce_circuit_dataflow_active", "bce_circuit_set_graph", "bce_circuit_graph_active", "bce_circuit_dataflow_plan", "bce_circuit_set_balance", "bce_circuit_relevel_steps", "bce_circuit_relevel_publications", "bce_circuit_check_relevel", "bce_circuit_set_instances", "bce_circuit_set_input", "bce_circuit_clock",
     "bce_circuit_get_output", "bce_circuit_get_buses", "bce_circuit_get_counts", "bce_circuit_get_stats", "bce_circuit_dump",
     "bce_circuit_set_exchange", "bce_circuit_enable_rccl", "bce_circuit_exchange_capacity", "bce_assemble_bristol", "bce_pool_gather",
     "bce_pool_scatter",
@@ -513,6 +514,7 @@ def _bind_circuit():
     L.bce_circuit_set_graph.argtypes = [vp, i32]
     L.bce_circuit_graph_active.argtypes = [vp]
     L.bce_circuit_get_encrypt_mode.argtypes = [vp]
+    L.bce_circuit_get_relevel.argtypes = [vp]
     L.bce_circuit_set_shard_locality.argtypes = [vp, i32]
     L.bce_circuit_plan_hash.argtypes = [vp]
     L.bce_circuit_plan_hash.restype = u64
@@ -669,8 +671,12 @@ class Circuit:
         self._ck(self._L.bce_circuit_set_xor_fast(self.h, int(b)))
 
     def setRelevel(self, b):
-        """opt-in: bootstrap-depth schedule (fewer dependent launches, same ciphertexts)"""
+        """bootstrap-depth schedule (fewer dependent launches, same ciphertexts): the default; False = the reference's
+        gate-level Clock rounds (src/circuit.cpp:532-573)"""
         self._ck(self._L.bce_circuit_set_relevel(self.h, int(b)))
+
+    def getRelevel(self):
+        return bool(self._L.bce_circuit_get_relevel(self.h))
 
     def setDataflow(self, b):
         """opt-in: the whole bootstrap DAG in one persistent launch (device-side ready-gate rule); before SetInput"""

@@ -1307,7 +1307,9 @@ Outputs Circuit::Clock() {
         boots0 = t.bootstraps;
     }
     size_t done_gates = 0;
-    const bool releveled = (relevel_ || dataflow_) && encrypted_flag && !plaintext_flag;
+    // gate-level rounds (the reference's Clock loop) whenever a plaintext pass rides along (verify mode) or the caller asked for
+    // one Gate::Evaluate per gate (setBatched(false)); otherwise the bootstrap-depth schedule, unless setRelevel(false)
+    const bool releveled = (relevel_ || dataflow_) && encrypted_flag && !plaintext_flag && batched_;
     if (releveled) {
         auto t0 = Clock_t::now();
         if (dataflowActive()) clockDataflow(); else clockReleveled();

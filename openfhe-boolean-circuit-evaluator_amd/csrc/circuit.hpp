@@ -241,7 +241,8 @@ private:
     void buildShardPlan();
     void instanceRange(unsigned& lo, unsigned& hi) const;
     struct RStep { std::vector<bce_gate_desc> descs; };
-    bool relevel_ = false;
+    bool relevel_ = true;   // the bootstrap-depth schedule is the default since round 4 (identical registers, 416 instead of 496
+                            // dependent launches on AES-expanded); setRelevel(false) = the reference's gate-level rounds, src/circuit.cpp:532-573
     std::vector<RStep> relevel_plan_;          // bootstrap-depth schedule (built lazily)
     std::vector<bce_gate_desc> relevel_nots_;  // NOT wires that OUTPUT gates read: materialised at the end
     uint32_t relevel_stride_ = 0, base_stride_ = 0, relevel_K_ = 0;

@@ -82,6 +82,7 @@ int bce_circuit_set_encrypt_mode(bce_circuit* h, int mode) {
 }
 int bce_circuit_set_xor_fast(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setXorFast(on != 0); }); }
 int bce_circuit_set_relevel(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setRelevel(on != 0); }); }
+int bce_circuit_get_relevel(bce_circuit* h) { return h && h->c.getRelevel() ? 1 : 0; }
 int bce_circuit_set_instances(bce_circuit* h, uint32_t k) { return guarded(h, [&] { h->c.setInstances(k); }); }
 int bce_circuit_set_shard_locality(bce_circuit* h, int on) { return guarded(h, [&] { h->c.setShardLocality(on != 0); }); }
 uint64_t bce_circuit_plan_hash(const bce_circuit* h) { return h ? h->c.planHash() : 0; }

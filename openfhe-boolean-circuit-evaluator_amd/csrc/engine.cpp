@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <unordered_set>
 #include <type_traits>
 #include <string>
 #include <vector>
@@ -67,7 +69,19 @@ bool os_entropy(uint8_t out[32]) {
 
 }  // namespace
 
+// Contexts that exist, and the schedules each one owns.  A bce_plan / bce_dag belongs to the context it was created on: the
+// context's destruction releases whatever its callers left behind, and bce_plan_destroy / bce_dag_destroy on a context that is
+// already gone (a Circuit destroyed after its engine) is a no-op instead of a read of freed memory.
+struct bce_plan;
+struct bce_dag;
+namespace {
+std::mutex g_live_mu;
+std::unordered_set<const bce_ctx*> g_live;
+}  // namespace
+
 struct bce_ctx {
+    std::unordered_set<bce_plan*> plans;
+    std::unordered_set<bce_dag*> dags;
     // parameters
     u32 n = 0, N = 0, logN = 0;
     u64 q = 0, Q = 0, qKS = 0, psi = 0;
@@ -172,6 +186,7 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     // partially built contexts are released through bce_ctx_destroy (frees whatever was allocated)
     struct CtxDeleter { void operator()(bce_ctx* p) const { bce_ctx_destroy(p); } };
     std::unique_ptr<bce_ctx, CtxDeleter> c(new bce_ctx);
+    { std::lock_guard<std::mutex> lk(g_live_mu); g_live.insert(c.get()); }
     c->n = n; c->N = N; c->q = q; c->Q = Q; c->qKS = qKS ? qKS : Q;
     c->baseKS = baseKS; c->baseG = baseG; c->baseR = baseR; c->method = method; c->device = device;
     while ((1u << c->logN) < N) ++c->logN;
@@ -678,12 +693,22 @@ int bce_ctx_create_custom(uint32_t n, uint32_t N, uint64_t q, uint64_t Q, uint64
     return build_ctx(n, N, q, Q, qKS, baseKS, baseG, baseR, method, device, out);
 }
 
+static void plan_free(bce_plan* p);
+static void dag_free(bce_dag* g);
+
 void bce_ctx_destroy(bce_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->rccl_comm) bce_rccl_shutdown(c);
     drain_timing(c);
+    {   // schedules nobody destroyed: theirs callers' handles die with the context
+        std::unordered_set<bce_plan*> plans;
+        std::unordered_set<bce_dag*> dags;
+        { std::lock_guard<std::mutex> lk(g_live_mu); plans.swap(c->plans); dags.swap(c->dags); g_live.erase(c); }
+        for (bce_plan* p : plans) plan_free(p);
+        for (bce_dag* g : dags) dag_free(g);
+    }
     for (auto& p : c->free_events) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (int i = 0; i < bce_ctx::kRing; ++i) {
         if (c->d_descs[i]) hipFree(c->d_descs[i]);
@@ -1078,13 +1103,22 @@ bool plan_capture_is_current(const bce_ctx* c, const bce_plan* p) {
 
 extern "C" {
 
-void bce_plan_destroy(bce_ctx* c, bce_plan* p) {
-    if (!p) return;
-    if (c) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); }
+static void plan_free(bce_plan* p) {
     if (p->exec) hipGraphExecDestroy(p->exec);
     if (p->graph) hipGraphDestroy(p->graph);
     hipFree(p->d_descs); hipFree(p->d_acc); hipFree(p->d_partial);
     delete p;
+}
+
+void bce_plan_destroy(bce_ctx* c, bce_plan* p) {
+    if (!p || !c) return;
+    {   // a context that no longer exists took its plans along (bce_ctx_destroy): nothing left to free, nothing to touch
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        if (!g_live.count(c) || !c->plans.erase(p)) return;
+    }
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    plan_free(p);
 }
 
 int bce_plan_create(bce_ctx* c, uint32_t n_steps, const uint32_t* step_sizes, const bce_gate_desc* descs, uint32_t instances,
@@ -1096,6 +1130,7 @@ int bce_plan_create(bce_ctx* c, uint32_t n_steps, const uint32_t* step_sizes, co
     HIP_TRY(c, hipSetDevice(c->device));
     struct Deleter { bce_ctx* c; void operator()(bce_plan* p) const { bce_plan_destroy(c, p); } };
     std::unique_ptr<bce_plan, Deleter> p(new bce_plan, Deleter{c});
+    { std::lock_guard<std::mutex> lk(g_live_mu); c->plans.insert(p.get()); }
     p->instances = instances; p->slot_stride = slot_stride;
     u64 total = 0;
     for (u32 s = 0; s < n_steps; ++s) {
@@ -1232,8 +1267,17 @@ int bce_dag_last_run(bce_ctx* c, uint64_t out[7]) {
 }
 
 void bce_dag_destroy(bce_ctx* c, bce_dag* g) {
-    if (!g) return;
-    if (c) { hipSetDevice(c->device); if (c->stream) hipStreamSynchronize(c->stream); }
+    if (!g || !c) return;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        if (!g_live.count(c) || !c->dags.erase(g)) return;
+    }
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    dag_free(g);
+}
+
+static void dag_free(bce_dag* g) {
     hipFree(g->d_tasks); hipFree(g->d_cons_off); hipFree(g->d_cons); hipFree(g->d_dep_init); hipFree(g->d_init); hipFree(g->d_qid);
     hipFree(g->d_dep); hipFree(g->d_ctl); hipFree(g->d_params);
     for (u32 q = 0; q < kDagQueues; ++q) hipFree(g->d_slots[q]);
@@ -1286,6 +1330,7 @@ int bce_dag_create(bce_ctx* c, uint32_t n_tasks, const bce_gate_desc* tasks, con
 
     struct Deleter { bce_ctx* c; void operator()(bce_dag* g) const { bce_dag_destroy(c, g); } };
     std::unique_ptr<bce_dag, Deleter> g(new bce_dag, Deleter{c});
+    { std::lock_guard<std::mutex> lk(g_live_mu); c->dags.insert(g.get()); }
     g->n_tasks = n_tasks; g->max_slot = max_slot; g->depth = depth; g->h_dep_init = dep;
     for (u32 q = 0; q < kDagQueues; ++q) {
         g->init_off[q] = (u32)g->init_items.size();
@@ -1387,6 +1432,7 @@ int bce_dag_run(bce_ctx* c, bce_dag* g, uint32_t instances, uint32_t slot_stride
     if (dbg && dbg[0] == 'd') D.policy |= 2u;
     // the XCD start gate pays where two workgroups per CU share the L2 in the saturated regime (development knob BCE_DAG_GATE=0 / 1)
     { const char* e = std::getenv("BCE_DAG_GATE"); if (e ? e[0] != '0' : wps == 4) D.policy |= 4u; }
+    { const char* e = std::getenv("BCE_DAG_TICKETS"); if (e && e[0] == '1') D.policy |= 8u; }   // development: round 3's claim rule
     const u32 grid = c->P.cu_count * (wps == 2 ? 1u : 2u);
     // parameter blocks reach the device in stream order (an earlier run may still be reading the previous ones) from
     // pinned staging entries that stay untouched until the next synchronisation

@@ -108,7 +108,8 @@ struct DagParams {
     u32 lazy_ticks;               // 100 MHz ticks a workgroup on a half-busy CU leaves a lone ready item to an idle CU
     u32 stall_ticks;              // 100 MHz ticks without any push after which a poller sets the abort word
     u32 policy;                   // bit 0: placement-aware claims (idle CUs first); bit 1: dry run (development);
-                                  // bit 2: workgroups of one XCD that claimed from a deep queue start their bootstraps together
+                                  // bit 2: workgroups of one XCD that claimed from a deep queue start their bootstraps together;
+                                  // bit 3: tickets for every claim (round 3's rule, kept for the A/B against the hybrid claim)
     u32 gate_ticks;               // longest wait at the XCD start gate (100 MHz ticks)
     u32 gate_backlog;             // queue depth at claim time from which a bootstrap goes through the gate
 };

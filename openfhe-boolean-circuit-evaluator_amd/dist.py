@@ -171,8 +171,7 @@ def check_against_single_rank(cc, circ, circuit_path, new_flag, relevel, instanc
     ref.Reset()
     ref.setEncrypted(True)
     ref.setEncryptMode(bce.FRESH)          # placeholders: the real input ciphertexts are copied in below
-    if relevel:
-        ref.setRelevel(True)
+    ref.setRelevel(bool(relevel))
     widths = [w for w in ref.info()["n_input_bits"] if w]
     for k in range(instances):
         ref.SetInput([[0] * w for w in widths], instance=k)

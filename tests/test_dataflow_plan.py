@@ -156,7 +156,17 @@ def test_reference_shaped_defaults(bce):
     assert c.getEncryptMode() == bce.FRESH
     with pytest.raises(bce.BceError):
         c.setEncryptMode(7)
-    assert not c.getDataflow() if hasattr(c, "getDataflow") else True
+    # the reference's call sequence (Circuit; ReadFile; Reset; setEncrypted; SetInput; Clock, src/test_aes.cpp:338-343) runs
+    # the register-identical bootstrap-depth schedule unless the caller asks for the gate-level rounds of
+    # src/circuit.cpp:532-573; Reset() clears the three mode flags like the reference's, not the schedule
+    assert c.getRelevel()
+    c.ReadFile(os.path.join(CIRCUITS, "adder_2bit.out"))
+    c.Reset()
+    assert c.getRelevel()
+    c.setRelevel(False)
+    assert not c.getRelevel()
+    c.Reset()
+    assert not c.getRelevel()
 
 
 def test_predicted_gate_sharding_curve_is_consistent(bce):

@@ -45,6 +45,12 @@ def test_adder_2bit_toy_encrypted_all_inputs(bce, toy_cc):
             o = _enc_run(c, [[a & 1, a >> 1], [b & 1, b >> 1]])
             assert o[0] + 2 * o[1] + 4 * o[2] == a + b
     st = c.stats()
+    assert c.getRelevel()                                   # default: bootstrap-depth schedule (XOR = 2 dependent steps)
+    assert st["bootstraps"] == 13 and st["verify_fixes"] == 0 and st["sublaunches"] == st["levels"]
+    c.setRelevel(False)                                     # the reference's Clock rounds: 4 levels, XOR levels in two stages
+    o = _enc_run(c, [[1, 1], [1, 0]])
+    assert o[0] + 2 * o[1] + 4 * o[2] == 4
+    st = c.stats()
     assert st["bootstraps"] == 13 and st["sublaunches"] == 5 and st["verify_fixes"] == 0
     assert c.counts() == {"input": 4, "output": 3, "not": 0, "and": 3, "or": 1, "xor": 3}
 
@@ -326,6 +332,7 @@ def test_relevelled_schedule_same_ciphertexts_fewer_launches(bce, toy_cc, std_cc
     c = bce.Circuit(toy_cc)
     c.ReadFile(os.path.join(CIRCUITS, "parity.out"))        # has NOT gates, one of them feeds an OUTPUT
     ins, want = kat.parity_case(3)
+    c.setRelevel(False)                                      # the reference's gate-level rounds first
     c.Reset(); c.setEncrypted(True); c.SetInput(ins)
     assert c.Clock()[0] == want
     lvl = toy_cc.lwe_read(np.arange(0, 27, dtype=np.uint32))
@@ -343,6 +350,7 @@ def test_relevelled_schedule_same_ciphertexts_fewer_launches(bce, toy_cc, std_cc
     m = bce.Circuit(std_cc)
     m.ReadBristol(os.path.join(CIRCUITS, "AES-expanded.txt"))
     v = [x for x in kat.AES_VECTORS if x["circuit"] == "AES-expanded"][0]
+    m.setRelevel(False)
     m.Reset(); m.setEncrypted(True); m.SetInput(kat.aes_case(v)[0])
     assert m.Clock()[0] == kat.aes_case(v)[1]
     assert m.stats()["sublaunches"] == 496

@@ -242,3 +242,54 @@ def test_sha256_dataflow_four_reference_vectors(bce, std):
     last = cc.dag_last_run()
     assert last["done"] == 354505 * len(vecs) and last["abort"] == 0
     c.close()
+
+
+def test_a_long_urgent_chain_does_not_park_the_chip(bce, std):
+    """claims were tickets (fetch-add) whenever a class showed ANY backlog, so at the start of a run
+    every eager workgroup took a ticket of the most urgent class, and those beyond its first entries then waited for FUTURE
+    entries of that class without looking at the others.  Two-class DAG that shows it: one chain of 100 dependent
+    bootstraps in class 0 and 65,536 independent ones in class 3.  Under the old rule (BCE_DAG_TICKETS=1) 99 workgroups
+    sit on tickets for chain links that arrive one bootstrap latency apart; with the hybrid claim (ticket only when the
+    backlog covers every poller, compare-and-swap of the observed head otherwise) idle workgroups take the wide work.
+    Checked on the scheduler's own counters: ticks spent looking for a bootstrap against ticks spent running one."""
+    _, cc = std
+    rng = np.random.default_rng(5)
+    chain, wide = 100, 65536            # the wide work outlasts the chain: nobody idles for lack of work
+    n_in = 2
+    tasks, prio = [], []
+    prev = 0
+    for i in range(chain):
+        tasks.append((bce.AND if i % 2 else bce.OR, prev, 1, n_in + i)); prio.append(0)
+        prev = n_in + i
+    for j in range(wide):
+        tasks.append((int(rng.choice([bce.AND, bce.NAND, bce.OR])), 0, 1, n_in + chain + j, j & 1, 0)); prio.append(3)
+    stride = n_in + len(tasks)
+    cc.pool_reserve(2 * stride)
+    cc.Encrypt(np.array([1, 1], dtype=np.uint8), np.array([0, 1], dtype=np.uint32))
+    cc.Encrypt(np.array([1, 1], dtype=np.uint8), np.array([stride, stride + 1], dtype=np.uint32))
+    cc.lwe_write([stride, stride + 1], cc.lwe_read([0, 1]))
+    for level in _levels(tasks):
+        cc.EvalGates(level)
+    want = cc.lwe_read(np.arange(0, stride, dtype=np.uint32))
+    ratios = {}
+    for rule in ("hybrid", "tickets"):
+        if rule == "tickets":
+            os.environ["BCE_DAG_TICKETS"] = "1"
+        try:
+            cc.dag_set_limits(workgroups_per_cu=2)
+            dag = cc.dag_create(tasks, prio=prio)
+            t0 = time.time()
+            cc.dag_run(dag, 1, stride, stride)
+            cc.synchronize()
+            dt = time.time() - t0
+        finally:
+            os.environ.pop("BCE_DAG_TICKETS", None)
+        last = cc.dag_last_run()
+        assert last["done"] == len(tasks) and last["abort"] == 0
+        assert np.array_equal(cc.lwe_read(np.arange(stride, 2 * stride, dtype=np.uint32)), want), rule
+        ratios[rule] = last["wait_ticks"] / max(1, last["busy_ticks"])
+        print("claim rule %-8s: %.3f s, wait / busy ticks = %.4f" % (rule, dt, ratios[rule]))
+        cc.dag_destroy(dag)
+    cc.dag_set_limits()
+    assert ratios["hybrid"] < 0.05, ratios
+    assert ratios["tickets"] > 4 * ratios["hybrid"], ratios

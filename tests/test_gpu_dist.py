@@ -34,8 +34,8 @@ def _worker(rank, world, port, shard_mode, K, q, relevel=False):
         cases = [kat.adder_case(t, 32) for t in range(K)]
         c.Reset()
         c.setEncrypted(True)
+        c.setRelevel(bool(relevel))
         if relevel:
-            c.setRelevel(True)
             c.check_relevel()
         for k, (ins, _) in enumerate(cases):
             c.SetInput(ins, instance=k)

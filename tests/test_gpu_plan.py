@@ -217,3 +217,39 @@ def test_events_off_counts_without_timing_and_leaves_the_same_ciphertexts(bce, s
     assert np.array_equal(cc.lwe_read(np.arange(stride, 2 * stride, dtype=np.uint32)), want)
     assert t1["bootstraps"] - t0["bootstraps"] == n_tasks and t1["blind_rotate_launches"] - t0["blind_rotate_launches"] == len(levels)
     assert t1["blind_rotate_ms"] == t0["blind_rotate_ms"] and t1["tail_ms"] == t0["tail_ms"]
+
+
+def test_an_engine_may_be_destroyed_before_its_circuits(bce):
+    """Every encrypted Clock() leaves a device-resident schedule (bce_plan; bce_dag under setDataflow) behind that the
+    circuit destroys with itself.  A host that tears down in the other order -- cc.close() before circ.close() -- must
+    not read freed memory: the context releases the schedules it still owns, the circuit's late destroy is a no-op."""
+    path = os.path.join(CIRCUITS, "adder_2bit.out")
+    for dataflow in (False, True):
+        cc = bce.BinFHEContext(bce.STD128_OPT, bce.GINX)
+        cc.KeyGen(3)
+        circs = []
+        for _ in range(2):
+            c = bce.Circuit(cc)
+            c.ReadFile(path)
+            if dataflow:
+                c.setDataflow(True)
+            c.Reset(); c.setEncrypted(True)
+            c.SetInput([[1, 1], [1, 0]])
+            out = c.Clock()[0]
+            assert out[0] + 2 * out[1] + 4 * out[2] == 4
+            circs.append(c)
+        circs[0].close()              # the usual order for one of them
+        cc.close()
+        circs[1].close()              # ... and the engine first for the other
+    # the engine-level handles behave the same way
+    cc = bce.BinFHEContext(bce.STD128_OPT, bce.GINX)
+    cc.KeyGen(4)
+    cc.pool_reserve(8)
+    plan = cc.plan_create([[(bce.AND, 0, 1, 2)]])
+    dag = cc.dag_create([(bce.AND, 0, 1, 2)])
+    h = cc.h
+    cc.close()
+    cc.h = h                          # a stale handle, as a C caller would hold it
+    cc.plan_destroy(plan)
+    cc.dag_destroy(dag)
+    cc.h = None

@@ -66,8 +66,7 @@ def main():
             c.Clock()
             want = [c.Outputs(k)[0] for k in range(K)]
             c.Reset(); c.setEncrypted(True)
-            if "bootstrap-depth" in name:
-                c.setRelevel(True)
+            c.setRelevel("bootstrap-depth" in name)
             sched_steps = None
             if "bootstrap-depth" in name:
                 sched_steps = len(c.relevel_steps())
