@@ -7,15 +7,18 @@ lock-step per GPU (K = 32 by default); every dependent step of the schedule goes
 HIP blind-rotation + key-switch kernels (`--schedule dataflow`: the whole DAG through bce_dag_run, one persistent launch).
 `--config N` selects another BASELINE.json config (2 adder_64bit, 4 sha256, 5 AES-expanded STD192 AP) with the same line.  Keys, parsing and input encryption are outside the timed
 region (input ciphertexts are resident in HBM when timing starts).  Multi-GPU (`--gpus N`, one
-rank per GPU under torch.distributed.run): keys replicated from the same seed, instances sharded
-over ranks (weak scaling, K per GPU), RCCL used only to exchange the final outputs
-(`--shard gates` instead shards every frontier and exchanges boundary ciphertexts over RCCL).
+rank per GPU under torch.distributed.run): keys replicated from the same seed, and -- north_star's partition --
+EVERY STEP'S READY GATES SPLIT OVER THE RANKS by bootstrap weight, K x N input blocks in lock-step (the per-GPU load
+of the one-GPU run: weak scaling), one RCCL all-gather per step of the outputs whose consumers sit on another rank.
+That run is the line's `value` for N > 1; at N = 1 it is the plain run, so SCALE(N = 1) = BENCH by construction.
+The collective-free form (every rank its own K blocks, nothing exchanged) rides along as `replicas`, the same
+partition at K blocks in total (strong scaling) as `shard_gates`; `--shard instances|gates-strong` make either the headline.
 
 `python3 bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) starts the N ranks itself: the parent
 spawns N fresh child processes of this script BEFORE anything touches the GPU (it never does itself), forwards
-rank 0's JSON line and exits non-zero if any child fails.  With N > 1 the line also carries a `shard_gates`
-object: the same circuit with every frontier's gates split over the ranks (north_star's partition, strong
-scaling, one allgather of boundary ciphertexts per level), timed over a few steps after the headline run.
+rank 0's JSON line and exits non-zero if any child fails.  The line carries `rccl`: the ranks the collective spans as
+counted BY the collective (all-reduce of ones; ncclCommCount of the library's own communicator for the in-library leg),
+the RCCL version, one device per rank, per-rank step times.
 
 Prints ONE JSON line on rank 0.
 """
@@ -177,9 +180,11 @@ def main():
                     help="steps: one launch per dependent step of the bootstrap-depth schedule (default); dataflow: the whole "
                          "bootstrap DAG in one persistent launch with device-side ready queues (bce_dag_*); graph: the step "
                          "schedule's launches replayed as one hipGraph per evaluation (bce_plan_run; timed as one unit)")
-    ap.add_argument("--shard", choices=["instances", "gates"], default="instances")
-    ap.add_argument("--no-gates-weak", dest="gates_weak", action="store_false",
-                    help="skip the secondary gate-sharded run at K x N input blocks (N > 1)")
+    ap.add_argument("--shard", choices=["gates", "instances", "gates-strong"], default="gates",
+                    help="N > 1 headline: gates = every step's gates split over the ranks, K x N blocks in lock-step (north_star's partition "
+                         "at the one-GPU load, weak scaling; default); instances = independent replicas, no data-path collective; "
+                         "gates-strong = the gate split at K blocks in total")
+    ap.add_argument("--replica-steps", type=int, default=2, help="N > 1: timed steps of the collective-free replica leg (0 = skip)")
     ap.add_argument("--no-relevel", dest="relevel", action="store_false",
                     help="schedule by gate level exactly like the reference's Clock() rounds (496 launches for AES) instead of "
                          "by bootstrap depth (416 launches, identical ciphertexts)")
@@ -192,8 +197,9 @@ def main():
     ap.add_argument("--no-block-latency", action="store_true",
                     help="skip the K = 1 single-block leg (profiled runs: keeps the kernel statistics to the timed workload)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--gates-timeout", type=int, default=300, help="N > 1: watchdog (s) over the secondary run and the teardown")
-    ap.add_argument("--gates-steps", type=int, default=2, help="N > 1: timed steps of the secondary gate-sharded run (0 = skip)")
+    ap.add_argument("--gates-timeout", type=int, default=540,
+                    help="N > 1: watchdog (s, from the moment the fallback line exists) over the gate-sharded runs and the teardown")
+    ap.add_argument("--gates-steps", type=int, default=2, help="N > 1: timed steps of the strong-scaling gate-sharded leg (0 = skip)")
     args = ap.parse_args()
     if args.config is not None:
         preset = {2: ("adder_64bit.txt", "STD128_OPT", "GINX", 256), 3: ("AES-expanded.txt", "STD128_OPT", "GINX", 32),
@@ -247,6 +253,7 @@ def main():
     keygen_s = time.time() - t_kg
     path = os.path.join(ROOT, "tests", "golden", "circuits", args.circuit)
     K_total = args.instances
+    first_run = {"t": None}
 
     def run_mode(shard_mode, steps, warmup, relevel, exchange="callback", K_run=None):
         """One timed run.  shard_mode 0 (instances): every rank evaluates ITS OWN K input blocks with its own
@@ -254,6 +261,9 @@ def main():
         script).  shard_mode 1 (gates): ONE set of K blocks, every level's gates split over the ranks by bootstrap
         weight, boundary ciphertexts exchanged per level (RCCL allgather)."""
         K_run = K_run or K_total
+        t_begin = time.time()
+        if first_run["t"] is None:
+            first_run["t"] = t_begin
         circ = bce.Circuit(cc)
         circ.ReadBristol(path, new_flag=args.circuit.startswith("sha256_new"))
         if args.xor_fast:
@@ -335,8 +345,12 @@ def main():
         verified = [circ.Outputs(k)[0] for k in range(K_run)] == expect
         st = circ.stats()
         total_boot = float(tm["bootstraps"])
+        per_rank_s = [elapsed]
         if dist is not None:
             t = torch.tensor([elapsed, total_boot, 0.0 if verified else 1.0, float(st["exchanged_cts"])], dtype=torch.float64, device=red_dev)
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            per_rank_s = [float(e[0]) for e in every]
             tmax = t.clone()
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -364,17 +378,101 @@ def main():
                         "registers_held_over_all_ranks": int(t[0]), "identical_to_single_rank_evaluation": bool(float(tmx[1]) == 0.0)}
             verified = verified and identity["identical_to_single_rank_evaluation"]
             cc.set_encrypt_seed(None)
+        rccl_info = None
+        if xch is not None and xch.in_library:
+            try:
+                rccl_info = cc.rccl_comm_info()      # ncclCommCount / rank / device of the communicator the exchange ran on
+            except Exception as e:
+                rccl_info = {"error": repr(e)}
         circ.close()
         return {"elapsed": elapsed, "total_boot": total_boot, "verified": verified, "tm": tm, "info": info, "relevel": relevel,
+                "K_run": K_run, "shard_mode": shard_mode if world > 1 else 0, "per_rank_ms_per_step": [round(x / steps * 1e3, 3) for x in per_rank_s],
+                "in_library_comm": rccl_info,
                 "launches_per_step": st["sublaunches"], "dataflow": df_active, "identity": identity,
                 "dag_last_run": cc.dag_last_run() if (args.schedule == "dataflow" and not gates) else None,
-                "exchanges_per_step": st["exchanges"], "exchanged_cts_per_step": xcts, "steps": steps, "t_ready": t_ready,
+                "exchanges_per_step": st["exchanges"], "exchanged_cts_per_step": xcts, "steps": steps, "t_ready": t_ready, "t_begin": t_begin,
                 "exchange_path": ("in-library ncclAllGather on the engine stream (no host sync)" if (xch is not None and xch.in_library) else
                                   ("torch.distributed all_gather_into_tensor callback after a stream sync" + (" [in-library RCCL unavailable: %s]" % xch.why if xch is not None and xch.why not in ("", "not requested") else "")) if xch is not None else "none")}
 
-    shard_mode = 0 if args.shard == "instances" else 1
-    R = run_mode(shard_mode, args.steps, args.warmup, args.relevel)
-    setup_s = R["t_ready"] - t_setup     # context + keygen + parsing + plaintext pass + input encryption
+    # ---- which run is the headline.  N = 1: the plain run.  N > 1: north_star's partition -- every step's gates split over the
+    # ranks, K x N blocks in lock-step (default); the collective-free replica run goes FIRST and short: it is the line that
+    # is printed if the gate-sharded run fails or never returns from a collective (watchdog below).
+    import threading
+    emit_lock = threading.Lock()
+    state = {"printed": False}
+    out = None
+    head_mode = {"gates": "gates", "instances": "instances", "gates-strong": "gates-strong"}[args.shard] if world > 1 else "single"
+    exch = os.environ.get("BCE_EXCHANGE", "callback")
+
+    def rccl_object():
+        """what the collective itself says it spans (N > 1)"""
+        ones = torch.ones(1, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)          # counted BY the collective: 1 from every rank it reaches
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "device": local_rank, "name": props.name, "uuid": str(getattr(props, "uuid", "")),
+                "pci_bus_id": getattr(props, "pci_bus_id", None)}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        ver = lib_ver = None
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+            lib_ver = int(bce.lib().bce_rccl_version()) or None      # ncclGetVersion of the librccl the engine dlopen()s
+        except Exception:
+            pass
+        return {"backend": "nccl (= RCCL on ROCm)" if backend == "nccl" else backend + " (rehearsal: not RCCL)",
+                "rccl_ranks": int(round(float(ones[0]))), "counted_by": "all-reduce(SUM) of 1 per rank over the process group the exchanges use",
+                "rccl_version": ver, "rccl_version_seen_by_the_library": lib_ver,
+                "devices": every, "distinct_devices": len({(d["device"], d["uuid"]) for d in every})}
+
+    REP = REP_err = None
+    block_latency_s = None
+    wd = None
+    if world > 1:
+        rccl_obj = rccl_object()
+        if head_mode != "instances" and args.replica_steps > 0:
+            try:
+                REP = run_mode(0, args.replica_steps, 1, args.relevel)
+            except Exception as e:
+                REP_err = repr(e)
+    shard_mode = 0 if head_mode in ("single", "instances") else 1
+    K_head = args.instances * world if head_mode == "gates" else args.instances
+
+    def on_timeout():
+        with emit_lock:
+            if rank == 0 and not state["printed"]:
+                msg = "the gate-sharded run / teardown did not finish within %d s: abandoned" % args.gates_timeout
+                if out is not None:
+                    out.setdefault("shard_gates", {"error": msg})
+                    emit()
+                elif REP is not None:
+                    fb = make_line(REP, "instances", args.replica_steps, 1)
+                    fb["error"] = "headline (gates split over the ranks) unavailable: " + msg + "; this line is the collective-free replica run"
+                    fb["headline_fallback"] = "replicas"
+                    fb["rccl"] = rccl_obj
+                    state["printed"] = True
+                    print(json.dumps(fb), flush=True)
+            sys.stderr.write("bench.py: rank %d watchdog fired after %d s\n" % (rank, args.gates_timeout))
+            sys.stderr.flush()
+            # a process that has touched the GPU and hangs in a collective is a FAILURE of the run: the line is out,
+            # the exit code says so (the parent prints "ranks failed"); no restart, no re-exec
+            os._exit(3)
+
+    if world > 1:
+        wd = threading.Timer(args.gates_timeout, on_timeout)
+        wd.daemon = True
+        wd.start()
+    R = R_err = None
+    try:
+        if os.environ.get("BCE_BENCH_TEST_HANG") == "head" and rank == world - 1:
+            time.sleep(1e6)          # test hook (tests/test_bench_launch.py): one rank never reaches the headline's collectives
+        R = run_mode(shard_mode, args.steps, args.warmup, args.relevel, exchange=exch, K_run=K_head)
+    except Exception as e:
+        if world == 1 or REP is None:
+            raise
+        R_err = repr(e)
+        sys.stderr.write("bench.py: rank %d: headline run failed: %s\n" % (rank, R_err))
+    if R is None:
+        R, head_mode = REP, "instances"     # the fallback line (error field set below)
     # SURVEY 8(d): also the end-to-end latency of ONE input block (K = 1: every dependent launch is a single narrow frontier)
     def single_block_latency():
         c1 = bce.Circuit(cc)
@@ -392,10 +490,7 @@ def main():
         dt = time.time() - t0
         c1.close()
         return dt
-    block_latency_s = None if args.no_block_latency else single_block_latency()
-    G = G_err = G2 = G2_err = None
-    out = None
-    elapsed, total_boot, verified, tm, info = R["elapsed"], R["total_boot"], R["verified"], R["tm"], R["info"]
+    block_latency_s = None if (args.no_block_latency or (world > 1 and R is REP)) else single_block_latency()
 
     def load_profile(name):
         try:
@@ -403,9 +498,15 @@ def main():
         except Exception:
             return None
 
-    default_cmd = (args.instances == 32 and args.circuit == "AES-expanded.txt" and args.paramset == "STD128_OPT" and args.method == "GINX"
-                   and shard_mode == 0 and R["relevel"] and not args.xor_fast and args.schedule == "steps")
-    if rank == 0:
+    def make_line(R, mode, steps, warmup):
+        """the JSON line of one timed run (rank 0).  mode: single | gates (K x N blocks, gates split) | gates-strong | instances"""
+        elapsed, total_boot, verified, tm, info = R["elapsed"], R["total_boot"], R["verified"], R["tm"], R["info"]
+        shard_mode = R["shard_mode"]
+        setup_s = first_run["t"] - t_setup + (R["t_ready"] - R["t_begin"])     # context + keygen, + this run's parsing, plaintext pass, input encryption
+        default_cmd = (args.instances == 32 and args.circuit == "AES-expanded.txt" and args.paramset == "STD128_OPT" and args.method == "GINX"
+                       and mode in ("single", "gates", "instances") and R["relevel"] and not args.xor_fast)
+        # the three schedules run the same blind-rotation body (lat_bootstrap): one instruction model for all of them
+        same_body = args.paramset in ("STD128_OPT", "STD128") and args.method == "GINX" and R["relevel"] and not args.xor_fast
         parts = cc.bytes_per_bootstrap_parts()         # {"bsk", "ksk", "ct"} at this build's widths (SURVEY 8(d) formula)
         bpb = parts["bsk"] + parts["ksk"] + parts["ct"]
         pr = cc.params
@@ -446,6 +547,7 @@ def main():
                                     "billed_to_this_kernel": br_bytes, "tail_fused_into_this_kernel": bool(fused)},
             "algorithmic_bytes_per_launch": br_bytes * per_launch,
             "compulsory_bytes_per_launch": compulsory,
+            "compulsory_frac": (compulsory / (avg_launch_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if avg_launch_ms > 0 else None,
             "counter_traffic_bytes_per_launch": traffic_bytes,
             "counter_traffic_frac_of_peak": (traffic_bytes / (avg_launch_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if traffic_bytes else None,
             "wasted_traffic_ratio": (traffic_bytes / compulsory) if traffic_bytes else None,
@@ -466,10 +568,11 @@ def main():
         # batch, the HBM convention exceeds 1 and says nothing; the kernel is bound by integer-VALU issue.  64-bit AP path
         # (config 5): the digit-selected keys are hardly shared, HBM binds first by the convention and fp64 issue is next.
         vm = None
-        if valu and not cfg5 and valu.get("bench_kernel") == dom["kernel"]:
+        if valu and not cfg5 and (valu.get("bench_kernel") == dom["kernel"] or (same_body and args.schedule in ("dataflow", "graph"))):
             simds = 4 * (valu.get("cu_count") or 256)
             vm = {"insts_per_bootstrap": valu["valu_insts_per_bootstrap"], "ns_per_wave_inst_per_simd": valu["ns_per_wave_inst_per_simd"], "simds": simds}
-            vm_src = "profiles/%s (SQ_INSTS_VALU of one saturated launch + instruction mix of the ISA + measured issue cost per opcode; committed constants, the launch time is this run's)" % valu_file
+            vm_src = "profiles/%s (SQ_INSTS_VALU of one saturated launch + instruction mix of the ISA + measured issue cost per opcode; committed constants, the launch time is this run's)%s" % (
+                valu_file, "" if valu.get("bench_kernel") == dom["kernel"] else "; counted on the per-step kernel %s, whose blind-rotation body this schedule's kernel shares" % valu.get("bench_kernel"))
         elif valu and cfg5 and "valu" in valu:
             vm = {"insts_per_bootstrap": valu["valu"]["insts_per_bootstrap"], "ns_per_wave_inst_per_simd": valu["valu"]["ns_per_wave_inst_per_simd"], "simds": 1024}
             vm_src = "profiles/%s (SQ_INSTS_VALU + fp64 issue cost of the step loop's mix; committed constants, the launch time is this run's)" % valu_file
@@ -487,7 +590,7 @@ def main():
                 roof[k] = valu_obj[k]
             roof["valu"] = valu_obj
             roof["hbm"] = hbm
-            for k in ("bytes_per_bootstrap", "algorithmic_bytes_per_launch", "compulsory_bytes_per_launch", "counter_traffic_bytes_per_launch",
+            for k in ("bytes_per_bootstrap", "algorithmic_bytes_per_launch", "compulsory_bytes_per_launch", "compulsory_frac", "counter_traffic_bytes_per_launch",
                       "counter_traffic_frac_of_peak", "wasted_traffic_ratio", "traffic_source"):
                 roof.pop(k, None)
             if not cfg5:
@@ -505,138 +608,137 @@ def main():
             "value": total_boot / elapsed,
             "unit": "gate-bootstraps/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak" if shard_mode == 0 else "strong",
+            "scaling": "strong" if mode == "gates-strong" else "weak",
             "vs_baseline": None,
             "dtype": "u32" if not cc.is64() else ("f64 (exact integers < 2^53 in IEEE doubles)" if cc.fp64() else "u64"),
             "data": "synthetic",
             "config": {
                 "workload": "%s (%d gates, %d gate-bootstraps/eval; %d kernel launches per evaluation as run) %s %s, "
-                            "%d input blocks in lock-step per GPU, verify off" % (
+                            "%s, verify off" % (
                                 args.circuit, info["n_gates"] - info["n_output_bits"], info["n_bootstraps"],
-                                R["launches_per_step"], args.paramset, args.method, args.instances),
+                                R["launches_per_step"], args.paramset, args.method,
+                                "%d input blocks in lock-step per GPU" % args.instances if mode in ("single", "instances") else
+                                "%d input blocks in lock-step, every step's ready gates split over the %d GPUs (%s)" % (
+                                    R["K_run"], world, "%d blocks per GPU: the one-GPU load" % args.instances if mode == "gates" else "strong scaling")),
                 "baseline_config": args.config if args.config is not None else (3 if default_cmd else None),
-                "instances_per_gpu": args.instances, "sharding": args.shard,
+                "instances_per_gpu": args.instances if mode != "gates-strong" else R["K_run"] / world, "instances_total": R["K_run"] * (world if mode == "instances" else 1),
+                "sharding": {"single": "none (one GPU)", "instances": "instances: independent replicas, no data-path collective",
+                             "gates": "gates: north_star's partition -- every step's ready gates split over the ranks by bootstrap weight, key replicated, "
+                                      "crossing outputs all-gathered after the step; K x N blocks in lock-step",
+                             "gates-strong": "gates, K blocks in total (strong scaling)"}[mode],
                 "schedule": ("dataflow: the whole bootstrap DAG in one persistent launch, device-side ready queues (identical ciphertexts)" if R["dataflow"] else
                              ("bootstrap-depth levels (NOTs folded, steps filled by slack up to the launch staircase, identical ciphertexts)" +
                               (", every evaluation's launches replayed as one hipGraph" if args.schedule == "graph" else "")) if R["relevel"] else "gate levels (reference Clock rounds)"),
                 "launches_per_step": R["launches_per_step"],
                 "reference_clock_rounds": info["n_levels"], "reference_sub_launches": info["n_sublaunches"],
                 "xor": "XOR_FAST (opt-in, 1 bootstrap)" if args.xor_fast else "NOT,NOT,AND,AND,OR (reference, 3 bootstraps)",
-                "bootstraps_per_step": int(total_boot / args.steps),
+                "bootstraps_per_step": int(total_boot / steps),
                 "forward_transforms_per_blind_rotation_step": cc.forward_transforms_per_step(),
-                "gates_per_s": (info["n_gates"] - info["n_output_bits"]) * args.instances * world * args.steps / elapsed,
+                "gates_per_s": (info["n_gates"] - info["n_output_bits"]) * R["K_run"] * (world if mode == "instances" else 1) * steps / elapsed,
                 "single_block_latency_s": None if block_latency_s is None else round(block_latency_s, 4),
                 "outputs_verified": bool(verified), "setup_s": round(setup_s, 2), "keygen_s": round(keygen_s, 3),
                 "input_encryption": ("FRESH (--fresh-inputs)" if args.fresh_inputs else
                                      "cc.Encrypt default of OpenFHE v1.0.x: BOOTSTRAPPED (one refresh bootstrap per input bit, %d per block, inside setup_s, outside the timed region)" % info["n_input_gates"]),
                 "host_share_of_step": round(1.0 - (tm["blind_rotate_ms"] + tm["tail_ms"]) / (elapsed * 1e3), 4),
                 "exchanges_per_step": R["exchanges_per_step"], "exchanged_cts_per_step": R["exchanged_cts_per_step"],
-                "collective": "none in the timed region (independent input blocks per rank)" if shard_mode == 0 else
-                              "one allgather of boundary ciphertexts per level (%s)" % backend,
+                "collective": "none in the timed region" if shard_mode == 0 else
+                              "one all-gather of the crossing outputs per step (%s); %s" % (backend, R["exchange_path"]),
+                "exchange_path": R["exchange_path"], "ciphertext_identity": R["identity"],
+                "per_rank_ms_per_step": R["per_rank_ms_per_step"],
             },
             "roofline": roof,
         }
 
-    # ---- the headline object exists from here on; everything below (secondary gate-sharded run on N > 1, teardown of the
-    # process group) runs under a watchdog, so that a collective that never returns costs the secondary object, not the line
-    import threading
-    emit_lock = threading.Lock()
-    state = {"printed": False}
+        return out
 
+    # ---- N > 1: assemble.  The fallback (replica) line exists since before the watchdog was armed; from here on everything
+    # runs under it, so that a collective that never returns costs the secondary objects, not the line.
     def emit():
         if rank == 0 and not state["printed"]:
             state["printed"] = True
             if not out.get("config", {}).get("outputs_verified", False):
-                out["error"] = "decrypted outputs differ from the plaintext evaluation"
+                out.setdefault("error", "decrypted outputs differ from the plaintext evaluation")
             print(json.dumps(out), flush=True)
 
-    def on_timeout():
-        with emit_lock:
-            if rank == 0 and not state["printed"]:
-                out["shard_gates"] = {"error": "gate-sharded secondary run / teardown did not finish within %d s: abandoned" % args.gates_timeout}
-                emit()
-            sys.stderr.write("bench.py: rank %d watchdog fired after %d s\n" % (rank, args.gates_timeout))
-            sys.stderr.flush()
-            # a process that has touched the GPU and hangs in a collective is a FAILURE of the run: the headline line is out,
-            # the exit code says so (the parent prints "ranks failed"); no restart, no re-exec
-            os._exit(3)
-
-    GW = GW_err = None
-    wd = None
-    if world > 1:
-        wd = threading.Timer(args.gates_timeout, on_timeout)
-        wd.daemon = True
-        wd.start()
-    if world > 1 and shard_mode == 0 and args.gates_steps > 0:
-        try:        # a failure of the secondary run must not cost the headline line
-            if os.environ.get("BCE_BENCH_TEST_HANG") == "1" and rank == world - 1:
-                time.sleep(1e6)      # test hook (tests/test_bench_launch.py): one rank never reaches the collective
-            G = run_mode(1, args.gates_steps, 1, args.relevel, exchange=os.environ.get("BCE_EXCHANGE", "callback"))
-        except Exception as e:
-            G_err = repr(e)
+    verified = R["verified"]
+    if rank == 0:
+        out = make_line(R, head_mode, R["steps"], args.warmup if R is not REP else 1)
+        if world > 1:
+            out["rccl"] = dict(rccl_obj, per_rank_ms_per_step=R["per_rank_ms_per_step"], exchange_path=R["exchange_path"])
+            if R is REP and args.shard != "instances":
+                out["error"] = "headline (gates split over the ranks) failed: %s; this line is the collective-free replica run" % R_err
+                out["headline_fallback"] = "replicas"
+            elif REP is not None:
+                out["replicas"] = {
+                    "what": "every rank its own %d blocks, no data-path collective (linear by construction): the per-GPU rate the gate-sharded headline is to be read against" % args.instances,
+                    "value": REP["total_boot"] / REP["elapsed"], "unit": "gate-bootstraps/s", "scaling": "weak", "steps": REP["steps"], "warmup": 1,
+                    "ms_per_step": REP["elapsed"] / REP["steps"] * 1e3, "per_rank_ms_per_step": REP["per_rank_ms_per_step"],
+                    "outputs_verified": bool(REP["verified"])}
+                out["headline_over_replicas"] = (R["total_boot"] / R["elapsed"]) / (REP["total_boot"] / REP["elapsed"])
+            elif REP_err is not None:
+                out["replicas"] = {"error": REP_err}
+    G = G_err = G2 = G2_err = None
+    if world > 1 and R is not REP and head_mode == "gates":
+        if args.gates_steps > 0:
+            try:        # a failure of a secondary run must not cost the headline line
+                if os.environ.get("BCE_BENCH_TEST_HANG") == "1" and rank == world - 1:
+                    time.sleep(1e6)      # test hook (tests/test_bench_launch.py): one rank never reaches the collective
+                G = run_mode(1, args.gates_steps, 1, args.relevel, exchange=exch)
+            except Exception as e:
+                G_err = repr(e)
         # the library's own RCCL all-gather on the engine stream has never run between two devices (no multi-GPU node was
-        # available to the builder): the verified torch.distributed callback carries the leg above, and this short extra
+        # available to the builder): the verified torch.distributed callback carries the legs above, and this short extra
         # leg puts the in-library path on record whenever a node is there (outputs verified like every other run)
-        if G is not None and backend == "nccl" and os.environ.get("BCE_EXCHANGE", "callback") != "rccl":
+        if backend == "nccl" and exch != "rccl" and G_err is None:
             try:
                 G2 = run_mode(1, 1, 1, args.relevel, exchange="rccl")
             except Exception as e:
                 G2_err = repr(e)
-        # north_star's partition at the K that saturates every GPU: K x world input blocks in lock-step, every step's gates
-        # split over the ranks -- per-GPU work is what one GPU does alone with K blocks ("weak" scaling of the gate-sharded mode)
-        if G is not None and args.gates_weak:
-            try:
-                GW = run_mode(1, 1, 1, args.relevel, exchange=os.environ.get("BCE_EXCHANGE", "callback"), K_run=args.instances * world)
-            except Exception as e:
-                GW_err = repr(e)
     if rank == 0:
-        if GW is not None or GW_err is not None:
-            out["shard_gates_weak"] = ({"error": GW_err} if GW is None else {
-                "what": "%d x %d input blocks in lock-step, every step's gates split over the %d ranks by bootstrap weight, one allgather of the "
-                        "crossing outputs per step: the gate-sharded partition at the per-GPU load of the headline run" % (args.instances, world, world),
-                "value": GW["total_boot"] / GW["elapsed"], "unit": "gate-bootstraps/s", "scaling": "weak",
-                "instances_total": args.instances * world, "ms_per_step": GW["elapsed"] / GW["steps"] * 1e3, "steps": GW["steps"], "warmup": 1,
-                "exchanges_per_step": GW["exchanges_per_step"], "exchanged_cts_per_step": GW["exchanged_cts_per_step"],
-                "exchange_path": GW["exchange_path"], "outputs_verified": bool(GW["verified"]), "ciphertext_identity": GW["identity"]})
-            if GW is not None:
-                try:
-                    pred = importlib.import_module("openfhe-boolean-circuit-evaluator_amd.predict")
-                    if args.paramset in ("STD128_OPT", "STD128") and GW["relevel"]:
-                        out["shard_gates_weak"]["predicted"] = pred.predict_gate_sharding(path, args.circuit.startswith("sha256_new"), args.instances, weak=True)
-                except Exception as e:
-                    out["shard_gates_weak"]["predicted"] = {"error": repr(e)}
+        pred = None
+        try:   # what the host-side model expects of this partition on 1, 2, 4, 8 GPUs (a prediction to check SCALE runs against)
+            pred = importlib.import_module("openfhe-boolean-circuit-evaluator_amd.predict")
+        except Exception:
+            pass
+        can_predict = pred is not None and args.paramset in ("STD128_OPT", "STD128") and R["relevel"]
+        if world > 1 and head_mode == "gates" and R is not REP and can_predict:
+            try:
+                out["predicted"] = pred.predict_gate_sharding(path, args.circuit.startswith("sha256_new"), args.instances, weak=True)
+            except Exception as e:
+                out["predicted"] = {"error": repr(e)}
         if G_err is not None:
             out["shard_gates"] = {"error": G_err}
         if G is not None:
             out["shard_gates"] = {
-                "what": "the same circuit and K, every step's gates split over the %d ranks by bootstrap weight (north_star's partition); "
-                        "boundary ciphertexts exchanged with one allgather per step (%s); %s" % (
-                            world, backend, "bootstrap-depth schedule, steps filled by slack up to the staircase of all ranks together"
+                "what": "the same partition at %d blocks IN TOTAL (strong scaling): every step's gates split over the %d ranks by bootstrap weight; "
+                        "crossing outputs exchanged with one all-gather per step (%s); %s" % (
+                            args.instances, world, backend, "bootstrap-depth schedule, steps filled by slack up to the staircase of all ranks together"
                             if G["relevel"] else "reference gate-level schedule"),
                 "value": G["total_boot"] / G["elapsed"], "unit": "gate-bootstraps/s", "scaling": "strong",
                 "ms_per_step": G["elapsed"] / G["steps"] * 1e3, "steps": G["steps"], "warmup": 1,
                 "exchanges_per_step": G["exchanges_per_step"], "exchanged_cts_per_step": G["exchanged_cts_per_step"],
-                "exchange_path": G["exchange_path"],
+                "exchange_path": G["exchange_path"], "per_rank_ms_per_step": G["per_rank_ms_per_step"],
                 "outputs_verified": bool(G["verified"]),
                 "ciphertext_identity": G["identity"],
             }
-            try:   # what the host-side model expects of this partition on 1, 2, 4, 8 GPUs (a prediction to check SCALE runs against)
-                pred = importlib.import_module("openfhe-boolean-circuit-evaluator_amd.predict")
-                if args.paramset in ("STD128_OPT", "STD128") and G["relevel"]:
+            if can_predict:
+                try:
                     out["shard_gates"]["predicted"] = pred.predict_gate_sharding(path, args.circuit.startswith("sha256_new"), args.instances)
-            except Exception as e:
-                out["shard_gates"]["predicted"] = {"error": repr(e)}
+                except Exception as e:
+                    out["shard_gates"]["predicted"] = {"error": repr(e)}
             if not G["verified"]:      # reported where it belongs; the headline run has its own flag (config.outputs_verified)
                 out["shard_gates"]["error"] = "decrypted outputs differ from the plaintext evaluation"
         if G2 is not None or G2_err is not None:
             out["shard_gates_in_library_rccl"] = ({"error": G2_err} if G2 is None else {
-                "what": "the same gate-sharded run with the exchange as ncclAllGather issued by the library on the engine stream (no host sync)",
+                "what": "the strong-scaling leg once more with the exchange as ncclAllGather issued by the library on the engine stream (no host sync)",
                 "value": G2["total_boot"] / G2["elapsed"], "unit": "gate-bootstraps/s", "ms_per_step": G2["elapsed"] / G2["steps"] * 1e3,
                 "steps": G2["steps"], "exchange_path": G2["exchange_path"], "outputs_verified": bool(G2["verified"]),
+                "rccl_ranks": (G2["in_library_comm"] or {}).get("ranks"), "communicator": G2["in_library_comm"],
+                "counted_by": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the library's own communicator (rank 0's view)",
                 "ciphertext_identity": G2["identity"]})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(path, args.paramset, args.method, args.cpu_seconds)

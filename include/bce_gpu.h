@@ -265,6 +265,9 @@ int bce_rccl_init(bce_ctx*, const uint8_t uid[128], int rank, int world);
  * ordered with the engine's kernels */
 int bce_rccl_allgather(bce_ctx*, const void* dev_send, void* dev_recv, uint64_t bytes);
 int bce_rccl_shutdown(bce_ctx*);
+/* what the context's communicator reports: out[0] = ncclCommCount (ranks RCCL sees), out[1] = ncclCommUserRank,
+ * out[2] = ncclCommCuDevice.  Lets a caller (bench.py, tests) prove what the exchange collective spans. */
+int bce_rccl_comm_info(bce_ctx*, int out[3]);
 
 /* ---- staged outputs for parity tests ----------------------------------- */
 /* Runs the frontier like bce_eval_gates and also returns the intermediates

@@ -60,7 +60,7 @@ ENGINE_SYMBOLS = [
     "bce_keygen", "bce_import_keys", "bce_import_keys_eval", "bce_export_bsk_eval", "bce_import_keys_file", "bce_export_keys_file", "bce_bsk_words", "bce_ksk_words", "bce_export_sk", "bce_export_bsk",
     "bce_export_ksk", "bce_pool_reserve", "bce_pool_slots", "bce_lwe_write", "bce_lwe_read",
     "bce_encrypt_bits", "bce_set_encrypt_seed", "bce_decrypt_bits", "bce_eval_gates", "bce_eval_gates_strided", "bce_synchronize",
-    "bce_timing_reset", "bce_timing_get", "bce_timing_set_events", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_forward_transforms_per_step", "bce_launch_capacity", "bce_rccl_available", "bce_rccl_version", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather",
+    "bce_timing_reset", "bce_timing_get", "bce_timing_set_events", "bce_bytes_per_bootstrap", "bce_bytes_per_bootstrap_parts", "bce_forward_transforms_per_step", "bce_launch_capacity", "bce_rccl_available", "bce_rccl_version", "bce_rccl_unique_id", "bce_rccl_init", "bce_rccl_allgather", "bce_rccl_comm_info",
     "bce_rccl_shutdown", "bce_debug_eval_stages", "bce_debug_ntt", "bce_debug_tail",
     "bce_dag_supported", "bce_dag_create", "bce_dag_run", "bce_dag_destroy", "bce_dag_set_limits", "bce_dag_last_run", "bce_dag_debug_block_task",
     "bce_plan_create", "bce_plan_run_step", "bce_plan_run", "bce_plan_destroy",
@@ -128,6 +128,7 @@ def lib():
     L.bce_rccl_init.argtypes = [vp, C.c_char_p, i32, i32]
     L.bce_rccl_allgather.argtypes = [vp, vp, vp, u64]
     L.bce_rccl_shutdown.argtypes = [vp]
+    L.bce_rccl_comm_info.argtypes = [vp, C.POINTER(C.c_int)]
     L.bce_debug_eval_stages.argtypes = [vp, u32, vp, vp, vp, vp]
     L.bce_debug_ntt.argtypes = [vp, vp, u32, i32]
     L.bce_debug_tail.argtypes = [vp, u32, vp, vp, vp, vp]
@@ -398,6 +399,12 @@ class BinFHEContext:
 
     def rccl_init(self, uid, rank, world):
         self._ck(self._L.bce_rccl_init(self.h, bytes(uid), int(rank), int(world)))
+
+    def rccl_comm_info(self):
+        """(ranks RCCL sees, this rank, HIP device) of the context's communicator"""
+        out = (C.c_int * 3)()
+        self._ck(self._L.bce_rccl_comm_info(self.h, out))
+        return {"ranks": int(out[0]), "rank": int(out[1]), "device": int(out[2])}
 
     def rccl_shutdown(self):
         self._ck(self._L.bce_rccl_shutdown(self.h))
