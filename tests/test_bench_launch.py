@@ -105,5 +105,6 @@ def test_bench_falls_back_to_the_replica_line_when_the_gate_sharded_headline_han
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1, p.stdout
     d = json.loads(line[0])
-    assert d["headline_fallback"] == "replicas" and "unavailable" in d["error"] and d["value"] > 0
+    # (the watchdog's message, or -- when the hung rank's own watchdog ended it first -- the collective's error on rank 0)
+    assert d["headline_fallback"] == "replicas" and ("unavailable" in d["error"] or "failed" in d["error"]) and d["value"] > 0
     assert d["config"]["sharding"].startswith("instances") and d["config"]["bootstraps_per_step"] == 2 * 4 * 310
