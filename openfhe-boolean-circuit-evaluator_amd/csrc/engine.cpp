@@ -94,6 +94,7 @@ struct bce_ctx {
     // device tables / keys
     uint2* d_twf = nullptr;
     u32* d_psi = nullptr;
+    u32* d_psi_r2 = nullptr;
     void* d_bsk = nullptr;       // u32 words (Q < 2^28) or u64 words (is64)
     ulonglong2* d_tw64 = nullptr;
     double2* d_tw64d = nullptr;   // (w, w / Q) for the double-precision formulation
@@ -230,6 +231,13 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     hipMemcpy(c->d_twf, twf.data(), sizeof(uint2) * N, hipMemcpyHostToDevice);
     if (hipMalloc(&c->d_psi, sizeof(u32) * N) != hipSuccess) { g_create_error = "hipMalloc(psi table) failed"; return BCE_ERR_HIP; }
     hipMemcpy(c->d_psi, psitab.data(), sizeof(u32) * N, hipMemcpyHostToDevice);
+    const u64 r2modq = c->is64 ? 0 : (u64)((((u128)1) << 64) % Q);     // R^2 mod Q, R = 2^32
+    {
+        std::vector<u32> t(N);
+        for (u32 i = 0; i < N; ++i) t[i] = c->is64 ? 0 : (u32)mul_mod(psitab[i], r2modq, Q);
+        if (hipMalloc(&c->d_psi_r2, sizeof(u32) * N) != hipSuccess) { g_create_error = "hipMalloc(psi table) failed"; return BCE_ERR_HIP; }
+        hipMemcpy(c->d_psi_r2, t.data(), sizeof(u32) * N, hipMemcpyHostToDevice);
+    }
     for (int i = 0; i < bce_ctx::kRing; ++i) hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming);
 
     DevParams& P = c->P;
@@ -266,7 +274,18 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         const bool ok3 = folded < ((u128)1 << (32 + P.red_shift));
         // (4) MAC keeps rp, rn < 3Q and acc < 2Q: 3Q*Q + 3Q*Q + 2Q below the Barrett bound, 3Q < 2^32
         const bool ok4 = (u128)6 * Q * Q + 2 * Q < ((u128)1 << (32 + P.red_shift)) && (u128)3 * Q < ((u128)1 << 32);
-        P.lazy = (ok1 && ok2 && ok3 && ok4) ? 1 : 0;
+        // (5) Montgomery form of the MAC tail (split-transform kernels): rp', rn' = REDC(sum) < sum / 2^32 + Q; the monomial
+        // factors are lazy in [0, 2Q); y = rp' M+ + rn' M- must fit 64 bits and REDC(y) < y / 2^32 + Q must stay <= 2Q, so that
+        // REDC(y) + acc (< 2Q) < 4Q < 2^32 and one conditional subtraction of 2Q returns it to [0, 2Q)
+        const u128 rmax = (sum >> 32) + 1 + Q, ymax = 2 * rmax * 2 * Q;
+        const bool ok5 = ymax < ((u128)1 << 64) && (ymax >> 32) + 1 + Q <= 2 * (u128)Q && (u128)4 * Q < ((u128)1 << 32);
+        P.lazy = (ok1 && ok2 && ok3 && ok4 && ok5) ? 1 : 0;
+    }
+    if (!c->is64) {
+        u32 inv = (u32)Q;                                  // Newton: inv = Q^-1 mod 2^32 (Q odd)
+        for (int i = 0; i < 5; ++i) inv *= 2u - (u32)Q * inv;
+        P.qinv_neg = 0u - inv;
+        P.r2_off = (u32)(Q - r2modq);
     }
     {
         const char* occ = std::getenv("BCE_OCCUPANCY");  // development knob: 2 or 3 workgroups per CU
@@ -294,6 +313,7 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     }
     P.tw_f = c->d_twf;
     P.psi_tab = c->d_psi;
+    P.psi_tab_r2 = c->d_psi_r2;
     P.is64 = c->is64 ? 1 : 0;
     P.Q64 = Q;
     P.Q8p1_64 = Q / 8 + 1;
@@ -717,7 +737,7 @@ void bce_ctx_destroy(bce_ctx* c) {
     }
     hipFree(c->d_io); if (c->h_io) hipHostFree(c->h_io);
     hipFree(c->d_P); if (c->h_dag_status) hipHostFree(c->h_dag_status); if (c->h_dag_stage) hipHostFree(c->h_dag_stage);
-    hipFree(c->d_twf); hipFree(c->d_psi); hipFree(c->d_tw64); hipFree(c->d_tw64d); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc); hipFree(c->d_tail_partial);
+    hipFree(c->d_twf); hipFree(c->d_psi); hipFree(c->d_psi_r2); hipFree(c->d_tw64); hipFree(c->d_tw64d); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc); hipFree(c->d_tail_partial);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }

@@ -622,6 +622,42 @@ __device__ __forceinline__ void ginx_mac_tail(const PT& P, __amdgpu_buffer_rsrc_
     *reinterpret_cast<uint4*>(accw) = make_uint4(a[0], a[1], a[2], a[3]);
 }
 
+// The same tail in Montgomery form (R = 2^32), for the split-transform kernels: REDC(x) = (x + ((u32) x * (-Q^-1)) Q) / 2^32
+// = x R^-1 mod Q, below x / 2^32 + Q, is TWO instructions (v_mul_lo_u32 + v_mad_u64_u32 -- the quotient is the high register of
+// the pair, no shift) where fold + Barrett is five.  rp' = REDC(sp) = sp R^-1, rn' likewise; the monomial factors come from a
+// table scaled by R^2, M = (psi^e - 1) R^2 lazily in [0, 2Q); REDC(rp' M+ + rn' M-) = sp (psi^e - 1) + sn (psi^-e - 1) mod Q,
+// below 2Q (bounds: engine.cpp, ok5), + acc (< 2Q) < 4Q, one conditional subtraction.  The accumulator words it leaves are
+// congruent to the Barrett form's and in the same range [0, 2Q); every reduced value downstream is therefore the same.
+__device__ __forceinline__ u32 redc(u64 x, u32 Q, u32 qn) { return (u32)(mad64((u32)x * qn, Q, x) >> 32); }
+template <int LOGN, typename PT>
+__device__ __forceinline__ void ginx_mac_tail_redc(const PT& P, __amdgpu_buffer_rsrc_t psi_r2_rsrc, u32 Q, u32 ap, uint2 Ia,
+                                                   uint2 Ina, u32 p0, const u32* accp, u32* accw, const u64 (&sp)[4],
+                                                   const u64 (&sn)[4], u32 (&a)[4]) {
+    constexpr u32 N = 1u << LOGN;
+    const bool odd = ap & 1u;
+    const u32 k0 = __brev(p0) >> (32 - LOGN);
+    const u32 ex = ((2 * k0 + 1) * ap) & (2 * N - 1);
+    const u32 off = P.r2_off, K = Q + 2 * off, qn = P.qinv_neg;     // -(M - off) + off = K - M
+    u32 mp[4], mn[4];
+    const u32 p0r = psi_pow<LOGN>(psi_r2_rsrc, ex, Q), n0r = psi_pow<LOGN>(psi_r2_rsrc, (2 * N - ex) & (2 * N - 1), Q);
+    mp[0] = p0r + off;
+    mn[0] = n0r + off;
+    mp[2] = csub(mul_shoup_lazy(p0r, Ia, Q), Q) + off;
+    mn[2] = csub(mul_shoup_lazy(n0r, Ina, Q), Q) + off;
+    mp[1] = odd ? K - mp[0] : mp[0];
+    mn[1] = odd ? K - mn[0] : mn[0];
+    mp[3] = odd ? K - mp[2] : mp[2];
+    mn[3] = odd ? K - mn[2] : mn[2];
+    const uint4 a4v = *reinterpret_cast<const uint4*>(accp);
+    a[0] = a4v.x; a[1] = a4v.y; a[2] = a4v.z; a[3] = a4v.w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const u32 rp = redc(sp[e], Q, qn), rn = redc(sn[e], Q, qn);
+        a[e] = csub(redc(mad64(rn, mn[e], mul64(rp, mp[e])), Q, qn) + a[e], 2 * Q);
+    }
+    *reinterpret_cast<uint4*>(accw) = make_uint4(a[0], a[1], a[2], a[3]);
+}
+
 // Common start of a gate bootstrap: twiddles into LDS, EvalBinGate's LWE preparation (ct1 + ct2 with the
 // folded EvalNOTs, or ct + q/4 for a refresh) into av[0..n], BootstrapGateCore's test vector into acc
 // (evaluation form).  Ends with a workgroup barrier.
@@ -1083,7 +1119,11 @@ __device__ __forceinline__ void lat_bootstrap(const PT& P, const bce_gate_desc g
     // GINX key: n * 2 RGSW ciphertexts; AP key: n * baseR * dR of them (< 2^31 bytes for every 32-bit parameter set)
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(P.bsk), 0, AP ? 0x7FFFFFFF : (int)(n * 2 * rgsw * 4), 0x00020000);
+#ifdef BCE_BARRETT_TAIL   // development: round 3's fold + Barrett tail, for the same-box A/B (tools/tail_ab.sh)
     const __amdgpu_buffer_rsrc_t psi_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(P.psi_tab), 0, N * 4, 0x00020000);
+#else
+    const __amdgpu_buffer_rsrc_t psi_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(P.psi_tab_r2), 0, N * 4, 0x00020000);
+#endif
     // digit extraction constants (see the throughput kernel)
     const u32 gb = P.gBits, Qh = Q >> 1;
     u32 off = 0;
@@ -1164,6 +1204,7 @@ __device__ __forceinline__ void lat_bootstrap(const PT& P, const bce_gate_desc g
         // with either, hence only in this build)
         // (folded key: the half-row waves 4..7 -- the younger ones, which the arbiter serves last -- one level above the
         // whole-row waves, so that both kinds finish the phase together: -2 % per saturated launch, profiles/r02_prio_ab.log)
+        // (round 4, profiles/r04_fwd_prio_ab.log: the whole-row waves above the half-row ones, or both at 1 -- within 0.3 % of this)
         if constexpr (WPS >= 4) { if (FOLD && wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #ifndef BCE_SKIP_FWD   // development: -DBCE_SKIP_FWD / -DBCE_SKIP_MAC leave a phase's LDS traffic out (wrong results) to
                        // attribute the LDS counters to phases, tools/lds_attribution.sh
@@ -1215,7 +1256,11 @@ __device__ __forceinline__ void lat_bootstrap(const PT& P, const bce_gate_desc g
                 const u32 a4 = ap & 3u;
                 const uint2 Ia = make_uint2(P.I4[a4], P.I4s[a4]);
                 const uint2 Ina = make_uint2(P.I4[(4u - a4) & 3u], P.I4s[(4u - a4) & 3u]);
+#ifdef BCE_BARRETT_TAIL
                 ginx_mac_tail<LOGN, true>(P, psi_rsrc, Q, ap, Ia, Ina, mp0, accr, accw, sp, sn, anew);
+#else
+                ginx_mac_tail_redc<LOGN>(P, psi_rsrc, Q, ap, Ia, Ina, mp0, accr, accw, sp, sn, anew);
+#endif
             }
             if constexpr (FOLD) cb = 2 * NP - cb;
             split_pass0(S, twf, anew, xa, Q, P.mu32);  // mc == c, mp0 == 4 t: this thread's pass-0 registers

@@ -47,6 +47,10 @@ struct DevParams {
     const uint2* tw_f;  // [N] (psi^brv(i), shoup), index m+i as in the CT forward NTT; the inverse
                         // transform derives psi^-k = -psi^(N-k) from the same table
     const u32* psi_tab; // [N] psi^e in natural exponent order (monomial lookups of the GINX MAC)
+    // Montgomery form of the GINX MAC tail in the split-transform kernels (R = 2^32, kernels.hip ginx_mac_tail_redc):
+    const u32* psi_tab_r2;  // [N] psi^e * R^2 mod Q
+    u32 qinv_neg;           // -Q^-1 mod 2^32
+    u32 r2_off;             // Q - (R^2 mod Q): psi^e R^2 + r2_off = (psi^e - 1) R^2 mod Q, lazily in [0, 2Q)
     const u32* bsk;     // EVALUATION domain, GINX [n][2][R][2][N]; AP [n][baseR][dR][R][2][N]
     // ---- 64-bit ring modulus path (kernels64.hip), used when is64 != 0 (Q >= 2^28) ----
     u32 is64;

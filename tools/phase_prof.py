@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-env = dict(os.environ, BCE_EXTRA_FLAGS="-DBCE_PHASE_PROF")
+env = dict(os.environ, BCE_EXTRA_FLAGS=(os.environ.get("BCE_EXTRA_FLAGS", "") + " -DBCE_PHASE_PROF").strip())   # other development flags ride along
 subprocess.check_call([sys.executable, os.path.join(ROOT, "openfhe-boolean-circuit-evaluator_amd", "build.py"), "--force"],
                       env=env, stdout=subprocess.DEVNULL)
 sys.path.insert(0, ROOT)
