@@ -360,10 +360,12 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
         for (u32 l = 0; l < c->dG; ++l) { span += pw; pw *= Bg; }
         const u128 hi = (Bg / 2 - 1) * span, lo = (Bg / 2) * span;       // largest / smallest (negated) representable value
         const bool exact = (u128)(Q >> 1) <= hi + 1 && (u128)(Q - (Q >> 1)) <= lo;
-        const bool has_kernel = c->is64 ? (P.fp64 && c->logN == 11 && c->dG == 3)                      // kernels64.hip, N = 2048
+        // (the folded fp64 kernels multiply a digit by a twiddle in one exact multiplication: |digit| Q <= (B / 2) Q < 2^53)
+        const bool has_kernel = c->is64 ? (P.fp64 && c->logN == 11 && c->dG == 3 && (Bg / 2) * (u128)Q < ((u128)1 << 53))   // kernels64.hip, N = 2048
                                          : (c->logN == 10 && c->dG == 4 && P.lazy && P.variant != 1);  // kernels.hip, split transform
         const char* fo = std::getenv("BCE_FOLD");
         P.fold = (exact && has_kernel && !(fo && fo[0] == '0')) ? 1 : 0;
+        P.fold_ninv = (BCE_KEY_NINV && P.fold && c->is64 && P.fp64) ? 1 : 0;
     }
     P.pool_stride = n + 1;
     c->enc_seed_ok = os_entropy(c->enc_seed);

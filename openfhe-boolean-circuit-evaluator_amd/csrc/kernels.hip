@@ -1790,8 +1790,15 @@ __global__ __launch_bounds__(256) void k_fold_gadget(DevParams P, W* __restrict_
             bl = (bl << P.gBits) % Q;
             const u64 t = (u64)(((unsigned __int128)bl * e0) % Q);
             W* w = base + (u64)(2 * l + c) * 2 * P.N + ck;
-            const u64 v = (u64)*w;
-            *w = (W)(dir > 0 ? (v >= t ? v - t : v + Q - t) : (v + t >= Q ? v + t - Q : v + t));
+            u64 v = (u64)*w;
+            if (dir > 0) {
+                v = v >= t ? v - t : v + Q - t;
+                if (P.fold_ninv) v = (u64)(((unsigned __int128)v * P.Ninv64) % Q);     // ... and scaled by N^-1
+            } else {
+                if (P.fold_ninv) v = (u64)(((unsigned __int128)v * P.N) % Q);
+                v = v + t >= Q ? v + t - Q : v + t;
+            }
+            *w = (W)v;
         }
     }
 }

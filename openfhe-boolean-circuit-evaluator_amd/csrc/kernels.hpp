@@ -15,6 +15,9 @@ using u32 = uint32_t;
 using u64 = uint64_t;
 
 // Everything a kernel needs, passed by value (lives in SGPRs / kernarg).
+#ifndef BCE_KEY_NINV
+#define BCE_KEY_NINV 1
+#endif
 struct DevParams {
     u32 n, N, logN;
     u32 q;            // LWE modulus, power of two
@@ -41,6 +44,9 @@ struct DevParams {
                            // transform kernel forced to its 256- / 128-register build (development knob BCE_VARIANT)
     u32 cu_count;          // compute units of the device (automatic choice: a launch of <= cu_count workgroups)
     u32 fuse_tail;         // 1: saturated launches of the split-transform kernel run the tail in their epilogue (BCE_FUSE_TAIL=0 disables)
+    u32 fold_ninv;         // 1 (folded fp64 kernels, kernels64.hip): rows l >= 1 of the key are also multiplied by N^-1 and the
+                           // evaluation-form accumulator is kept scaled by N^-1, so that the un-normalised inverse transform yields
+                           // the coefficients themselves (no N^-1 product per coefficient and step; -DBCE_KEY_NINV=0 disables)
     u32 fold;              // 1: the key is stored with the lowest gadget digit folded in (rows l >= 1 hold ek_l - B^l ek_0) and
                            // the kernels multiply the digit-0 rows by the evaluation-form accumulator itself (BCE_FOLD=0 disables)
     u32 I4[4], I4s[4];     // powers of I = psi^(N/2) (primitive 4th root of unity) and Shoup companions

@@ -533,6 +533,11 @@ using w64::gate_const;
 struct Tw {
     const double2* __restrict__ g;   // global, [N]
     const double2* l;                // LDS mirror of g[0 .. TW_LDS), or unused
+    // W1 builds (folded key, N = 2048; round 4): the LDS mirror holds ALL N entries as plain doubles -- the value w only, 8 bytes
+    // instead of (w, w / Q) -- and the quotient estimate comes from the product itself (modmul: rint(h * invQ) instead of
+    // rint(y * (w / Q)), same six operations).  Half the twiddle bytes through LDS, no twiddle left in global memory.
+    const double* l1 = nullptr;
+    double invQ = 0.0;
     template <u32 M, u32 TW_LDS>
     __device__ __forceinline__ const double2* blk() const { return (2 * M <= TW_LDS) ? l : g; }
 };
@@ -550,6 +555,29 @@ __device__ __forceinline__ double modmul(double y, double w, double invQ, double
     return fma(-q, Q, h) + l;
 }
 __device__ __forceinline__ double modred(double s, double invQ, double Q) { return fma(-rint(s * invQ), Q, s); }
+// y * twiddle mod Q for either kind of table entry: (w, w / Q) pairs, or w alone (W1 builds).  Error of the quotient estimate
+// for |y| < 2^49, w < Q < 2^39: below 0.125 with the pair, below 0.19 with w alone (three roundings: h, 1 / Q, their product),
+// i.e. |result| <= 0.625 Q / 0.69 Q -- both inside the bounds the transforms are laid out for (inverse: sums of 2^11 values
+// stay below 2^49; forward: 11 stages grow a 13-bit digit to < 7.6 Q < 2^40).
+__device__ __forceinline__ double tmul(double y, double2 w, const Tw&, double Q) { return modmul_q(y, w.x, w.y, Q); }
+__device__ __forceinline__ double tmul(double y, double w, const Tw& t, double Q) { return modmul(y, w, t.invQ, Q); }
+// a 13-bit digit times a twiddle is below 2^53: the product is exact in ONE multiplication (no low part to recover)
+__device__ __forceinline__ double tmul_digit(double d, double2 w, const Tw& t, double Q) { return modmul_q(d, w.x, w.y, Q); }
+__device__ __forceinline__ double tmul_digit(double d, double w, const Tw& t, double Q) {
+    const double h = d * w;
+    return fma(-rint(h * t.invQ), Q, h);
+}
+template <bool W1> struct TwSel;
+template <> struct TwSel<false> {
+    typedef double2 T;
+    static __device__ __forceinline__ double2 lds(const Tw& t, u32 i) { return t.l[i]; }
+    static __device__ __forceinline__ double2 last(const Tw& t, u32 i) { return t.g[i]; }   // block m = N / 2: global memory
+};
+template <> struct TwSel<true> {
+    typedef double T;
+    static __device__ __forceinline__ double lds(const Tw& t, u32 i) { return t.l1[i]; }
+    static __device__ __forceinline__ double last(const Tw& t, u32 i) { return t.l1[i]; }
+};
 
 template <int LOGN, int LO>
 __device__ __forceinline__ void load_pass(const double* poly, u32 lane, double (&x)[Cfg<LOGN>::E]) {
@@ -715,9 +743,11 @@ __device__ __forceinline__ void forward_phase_balanced(double* dct, int NP, Tw t
 // One HALF of a forward transform (stages on bits 7..0; bits 10, 9, 8 were applied by the producer) by one wave:
 // 128 virtual lanes per polynomial, v = half * 64 + lane, 16 coefficients per lane (bits 7..4, then 3..0), one
 // workgroup barrier between the two passes (the two halves exchange data), executed by every wave of the workgroup.
-template <int LOGN>
+template <int LOGN, bool W1 = false>
 __device__ __forceinline__ void forward_half(double* poly, Tw twa, u32 v, double Q) {
     static_assert(LOGN == 11, "laid out for N = 2048");
+    typedef TwSel<W1> TS;
+    typedef typename TS::T TV;
     double x[16];
         {   // pass A: registers = position bits 7..4; v[3:0] = p[3:0], v[6:4] = p[10:8]
             const u32 hi = v >> 4, base = (hi << 8) | (v & 15u);
@@ -727,13 +757,12 @@ __device__ __forceinline__ void forward_half(double* poly, Tw twa, u32 v, double
             for (int B = 7; B >= 4; --B) {           // stage on bit B = register bit B - 4; twiddle tw[m + (p >> (B+1))]
                 const int rb = B - 4;
                 const u32 m = 1u << (10 - B);
-                const double2* tw = twa.l;  // m <= 64: LDS mirror
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (r & (1 << rb)) continue;
-                    const double2 w = tw[m + ((hi << (7 - B)) | (u32)(r >> (rb + 1)))];
+                    const TV w = TS::lds(twa, m + ((hi << (7 - B)) | (u32)(r >> (rb + 1))));   // m <= 64: LDS mirror
                     const double X = x[r];
-                    const double T = modmul_q(x[r | (1 << rb)], w.x, w.y, Q);
+                    const double T = tmul(x[r | (1 << rb)], w, twa, Q);
                     x[r] = X + T;
                     x[r | (1 << rb)] = X - T;
                 }
@@ -749,13 +778,13 @@ __device__ __forceinline__ void forward_half(double* poly, Tw twa, u32 v, double
 #pragma unroll
             for (int B = 3; B >= 0; --B) {
                 const u32 m = 1u << (10 - B);
-                const double2* tw = (B == 0) ? twa.g : twa.l;  // only the block of the last stage (m = 1024) is global
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (r & (1 << B)) continue;
-                    const double2 w = tw[m + ((v << (3 - B)) | (u32)(r >> (B + 1)))];
+                    const u32 ti = m + ((v << (3 - B)) | (u32)(r >> (B + 1)));
+                    const TV w = (B == 0) ? TS::last(twa, ti) : TS::lds(twa, ti);  // only the block of the last stage (m = 1024) is global (W1: LDS)
                     const double X = x[r];
-                    const double T = modmul_q(x[r | (1 << B)], w.x, w.y, Q);
+                    const double T = tmul(x[r | (1 << B)], w, twa, Q);
                     x[r] = X + T;
                     x[r | (1 << B)] = X - T;
                 }
@@ -769,32 +798,35 @@ __device__ __forceinline__ void forward_half(double* poly, Tw twa, u32 v, double
 // wave needs nobody else's data -- 64 lanes x 8 coefficients, passes on bits 7..5 / 4..2 / 1..0, two WAVE-LOCAL
 // re-shuffles, no workgroup barrier.  The folded 16-wave kernel runs its four digit rows as 16 of these, one per wave
 // (four per SIMD); the folded 8-wave kernel runs two per wave.
-__device__ __forceinline__ void fwd_bfly_d(double& X, double& Y, double2 w, double Q) {
-    const double T = modmul_q(Y, w.x, w.y, Q);
+template <typename TV>
+__device__ __forceinline__ void fwd_bfly_d(double& X, double& Y, TV w, const Tw& twa, double Q) {
+    const double T = tmul(Y, w, twa, Q);
     Y = X - T;
     X = X + T;
 }
-template <int LOGN>
+template <int LOGN, bool W1 = false>
 __device__ __forceinline__ void forward_quarter(double* row, u32 k, Tw twa, u32 lane, double Q) {
     static_assert(LOGN == 11, "laid out for N = 2048");
-    const double2* twl = twa.l;   // blocks m <= 512 sit in the LDS mirror, the block of the last stage (m = 1024) in global memory
+    // blocks m <= 512 sit in the LDS mirror; the block of the last stage (m = 1024) in global memory, or (W1) in LDS too
+    typedef TwSel<W1> TS;
+    typedef typename TS::T TV;
     double x[8];
     {   // coefficients = bits 7..5, lane = (bit 8, bits 4..0)
         const u32 l8 = lane >> 5, hi = (k << 1) | l8;
         double* const p = row + phys((k << 9) | (l8 << 8) | (lane & 31u));   // coefficient r: + 32 r
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = p[(r >> 1) * 68 + (r & 1) * 32];
-        const double2 w7 = twl[8 + hi];                                       // stage on bit B: tw[m + (p >> (B + 1))], m = 2^(10 - B)
+        const TV w7 = TS::lds(twa, 8 + hi);                                       // stage on bit B: tw[m + (p >> (B + 1))], m = 2^(10 - B)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) fwd_bfly_d(x[r], x[r + 4], w7, Q);
+        for (int r = 0; r < 4; ++r) fwd_bfly_d(x[r], x[r + 4], w7, twa, Q);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const double2 w6 = twl[16 + ((hi << 1) | g)];
-            fwd_bfly_d(x[4 * g], x[4 * g + 2], w6, Q);
-            fwd_bfly_d(x[4 * g + 1], x[4 * g + 3], w6, Q);
+            const TV w6 = TS::lds(twa, 16 + ((hi << 1) | g));
+            fwd_bfly_d(x[4 * g], x[4 * g + 2], w6, twa, Q);
+            fwd_bfly_d(x[4 * g + 1], x[4 * g + 3], w6, twa, Q);
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) fwd_bfly_d(x[2 * g], x[2 * g + 1], twl[32 + ((hi << 2) | g)], Q);
+        for (int g = 0; g < 4; ++g) fwd_bfly_d(x[2 * g], x[2 * g + 1], TS::lds(twa, 32 + ((hi << 2) | g)), twa, Q);
 #pragma unroll
         for (int r = 0; r < 8; ++r) p[(r >> 1) * 68 + (r & 1) * 32] = x[r];
     }
@@ -804,17 +836,17 @@ __device__ __forceinline__ void forward_quarter(double* row, u32 k, Tw twa, u32 
         double* const p = row + phys((k << 9) | (lh << 5) | (lane & 3u));       // coefficient r: + 4 r, inside one 64-block
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = p[4 * r];
-        const double2 w4 = twl[64 + hi];
+        const TV w4 = TS::lds(twa, 64 + hi);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) fwd_bfly_d(x[r], x[r + 4], w4, Q);
+        for (int r = 0; r < 4; ++r) fwd_bfly_d(x[r], x[r + 4], w4, twa, Q);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const double2 w3 = twl[128 + ((hi << 1) | g)];
-            fwd_bfly_d(x[4 * g], x[4 * g + 2], w3, Q);
-            fwd_bfly_d(x[4 * g + 1], x[4 * g + 3], w3, Q);
+            const TV w3 = TS::lds(twa, 128 + ((hi << 1) | g));
+            fwd_bfly_d(x[4 * g], x[4 * g + 2], w3, twa, Q);
+            fwd_bfly_d(x[4 * g + 1], x[4 * g + 3], w3, twa, Q);
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) fwd_bfly_d(x[2 * g], x[2 * g + 1], twl[256 + ((hi << 2) | g)], Q);
+        for (int g = 0; g < 4; ++g) fwd_bfly_d(x[2 * g], x[2 * g + 1], TS::lds(twa, 256 + ((hi << 2) | g)), twa, Q);
 #pragma unroll
         for (int r = 0; r < 8; ++r) p[4 * r] = x[r];
     }
@@ -826,12 +858,12 @@ __device__ __forceinline__ void forward_quarter(double* row, u32 k, Tw twa, u32 
         x[0] = v0.x; x[1] = v0.y; x[2] = v1.x; x[3] = v1.y; x[4] = v2.x; x[5] = v2.y; x[6] = v3.x; x[7] = v3.y;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const double2 w1 = twl[512 + ((hl << 1) | g)];
-            fwd_bfly_d(x[4 * g], x[4 * g + 2], w1, Q);
-            fwd_bfly_d(x[4 * g + 1], x[4 * g + 3], w1, Q);
+            const TV w1 = TS::lds(twa, 512 + ((hl << 1) | g));
+            fwd_bfly_d(x[4 * g], x[4 * g + 2], w1, twa, Q);
+            fwd_bfly_d(x[4 * g + 1], x[4 * g + 3], w1, twa, Q);
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) fwd_bfly_d(x[2 * g], x[2 * g + 1], twa.g[1024 + ((hl << 2) | g)], Q);
+        for (int g = 0; g < 4; ++g) fwd_bfly_d(x[2 * g], x[2 * g + 1], TS::last(twa, 1024 + ((hl << 2) | g)), twa, Q);
         p[0] = make_double2(x[0], x[1]); p[1] = make_double2(x[2], x[3]); p[2] = make_double2(x[4], x[5]); p[3] = make_double2(x[6], x[7]);
     }
     wave_sync();
@@ -886,48 +918,52 @@ __device__ __forceinline__ double2 key_row(__amdgpu_buffer_rsrc_t rsrc, u32 voff
 // they need no workgroup barrier.  Only the exchange before the last pass (position bits 10:9 <-> wave) crosses waves.
 // No reduction anywhere (see the bounds above); the caller multiplies by N^-1.
 // three Gentleman-Sande stages on the register index bits 0,1,2; twiddles: f0[4] (bit 0), f1[2] (bit 1), f2 (bit 2)
-__device__ __forceinline__ void inv_pass8(double (&x)[8], const double2 (&f0)[4], const double2 (&f1)[2], double2 f2, double Q) {
+template <typename TV>
+__device__ __forceinline__ void inv_pass8(double (&x)[8], const TV (&f0)[4], const TV (&f1)[2], TV f2, const Tw& twa, double Q) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {  // pairs (2k, 2k+1): index bits above bit 0 = k
         const double X = x[2 * k], Y = x[2 * k + 1];
         x[2 * k] = X + Y;
-        x[2 * k + 1] = modmul_q(Y - X, f0[k].x, f0[k].y, Q);
+        x[2 * k + 1] = tmul(Y - X, f0[k], twa, Q);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {  // pairs (r, r+2), r = (k>>1)*4 + (k&1): twiddle by r >> 2
         const int r = (k >> 1) * 4 + (k & 1);
         const double X = x[r], Y = x[r + 2];
         x[r] = X + Y;
-        x[r + 2] = modmul_q(Y - X, f1[k >> 1].x, f1[k >> 1].y, Q);
+        x[r + 2] = tmul(Y - X, f1[k >> 1], twa, Q);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {  // pairs (r, r+4)
         const double X = x[r], Y = x[r + 4];
         x[r] = X + Y;
-        x[r + 4] = modmul_q(Y - X, f2.x, f2.y, Q);
+        x[r + 4] = tmul(Y - X, f2, twa, Q);
     }
 }
 // inverse twiddle of stage B for stage index i: -tw[(2m - 1) - i], m = 2^(LOGN-1-B); the sign sits in the operand
-template <int B>
-__device__ __forceinline__ double2 itw11(Tw tw, u32 i) {
+template <int B, bool W1 = false>
+__device__ __forceinline__ typename TwSel<W1>::T itw11(Tw tw, u32 i) {
     constexpr u32 m = 1u << (10 - B);
-    return tw.blk<m, 1024>()[(2 * m - 1) - i];
+    if constexpr (W1) return tw.l1[(2 * m - 1) - i];
+    else return tw.blk<m, 1024>()[(2 * m - 1) - i];
 }
 // acc: evaluation-form polynomial (padded natural layout); bufA / bufB: >= 2112 doubles each; t = thread in the
 // 256-thread group.  Leaves coefficient j = (r << 8) | t in x[r] (before the N^-1 scaling).  INV_BARRIERS workgroup
 // barriers; bufA must not be written by anyone until the caller's next barrier (pass 3 reads it).
+template <bool W1 = false>
 __device__ __forceinline__ void split_inverse11(const double* src, double* bufA, double* bufB, Tw tw, u32 t, double Q,
                                                 double (&x)[8]) {
-    double2 f0[4], f1[2], f2;
+    typedef typename TwSel<W1>::T TV;
+    TV f0[4], f1[2], f2;
     {   // pass 0: p = 8t + r
         const double2* sp = reinterpret_cast<const double2*>(src + phys(8 * t));
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const double2 v = sp[k]; x[2 * k] = v.x; x[2 * k + 1] = v.y; }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) f0[k] = itw11<0>(tw, 4 * t + k);
-        f1[0] = itw11<1>(tw, 2 * t); f1[1] = itw11<1>(tw, 2 * t + 1);
-        f2 = itw11<2>(tw, t);
-        inv_pass8(x, f0, f1, f2, Q);
+        for (int k = 0; k < 4; ++k) f0[k] = itw11<0, W1>(tw, 4 * t + k);
+        f1[0] = itw11<1, W1>(tw, 2 * t); f1[1] = itw11<1, W1>(tw, 2 * t + 1);
+        f2 = itw11<2, W1>(tw, t);
+        inv_pass8(x, f0, f1, f2, tw, Q);
 #pragma unroll
         for (int r = 0; r < 8; ++r) bufA[r * 257 + t] = x[r];          // e0
     }
@@ -937,10 +973,10 @@ __device__ __forceinline__ void split_inverse11(const double* src, double* bufA,
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = bufA[l * 257 + ((g << 3) | (u32)r)];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) f0[k] = itw11<3>(tw, 4 * g + k);
-        f1[0] = itw11<4>(tw, 2 * g); f1[1] = itw11<4>(tw, 2 * g + 1);
-        f2 = itw11<5>(tw, g);
-        inv_pass8(x, f0, f1, f2, Q);
+        for (int k = 0; k < 4; ++k) f0[k] = itw11<3, W1>(tw, 4 * g + k);
+        f1[0] = itw11<4, W1>(tw, 2 * g); f1[1] = itw11<4, W1>(tw, 2 * g + 1);
+        f2 = itw11<5, W1>(tw, g);
+        inv_pass8(x, f0, f1, f2, tw, Q);
 #pragma unroll
         for (int r = 0; r < 8; ++r) bufB[r * 264 + t] = x[r];          // e1 (t = (g << 3) | l)
     }
@@ -950,10 +986,10 @@ __device__ __forceinline__ void split_inverse11(const double* src, double* bufA,
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = bufB[(m >> 3) * 264 + ((((h << 3) | (u32)r) << 3) | (m & 7u))];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) f0[k] = itw11<6>(tw, 4 * h + k);
-        f1[0] = itw11<7>(tw, 2 * h); f1[1] = itw11<7>(tw, 2 * h + 1);
-        f2 = itw11<8>(tw, h);
-        inv_pass8(x, f0, f1, f2, Q);
+        for (int k = 0; k < 4; ++k) f0[k] = itw11<6, W1>(tw, 4 * h + k);
+        f1[0] = itw11<7, W1>(tw, 2 * h); f1[1] = itw11<7, W1>(tw, 2 * h + 1);
+        f2 = itw11<8, W1>(tw, h);
+        inv_pass8(x, f0, f1, f2, tw, Q);
 #pragma unroll
         for (int r = 0; r < 8; ++r) bufA[r * 257 + t] = x[r];          // e2 (t = (h << 6) | m)
     }
@@ -961,20 +997,20 @@ __device__ __forceinline__ void split_inverse11(const double* src, double* bufA,
     {   // pass 3: p = (r << 8) | t; e2 address of p: p[8:6] * 257 + (p[10:9] << 6 | p[5:0]); stages on bits 9, 10
 #pragma unroll
         for (int r = 0; r < 8; ++r) x[r] = bufA[((((u32)r & 1u) << 2) | (t >> 6)) * 257 + ((((u32)r >> 1) << 6) | (t & 63u))];
-        const double2 g0 = itw11<9>(tw, 0), g1 = itw11<9>(tw, 1), g2 = itw11<10>(tw, 0);
+        const TV g0 = itw11<9, W1>(tw, 0), g1 = itw11<9, W1>(tw, 1), g2 = itw11<10, W1>(tw, 0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {  // bit 9 = register bit 1: pairs (r, r+2), r in {0,1,4,5}; stage index = r >> 2
             const int r = (k >> 1) * 4 + (k & 1);
             const double X = x[r], Y = x[r + 2];
             x[r] = X + Y;
-            const double2 f = (k >> 1) ? g1 : g0;
-            x[r + 2] = modmul_q(Y - X, f.x, f.y, Q);
+            const TV f = (k >> 1) ? g1 : g0;
+            x[r + 2] = tmul(Y - X, f, tw, Q);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {  // bit 10 = register bit 2
             const double X = x[r], Y = x[r + 4];
             x[r] = X + Y;
-            x[r + 4] = modmul_q(Y - X, g2.x, g2.y, Q);
+            x[r + 4] = tmul(Y - X, g2, tw, Q);
         }
     }
 }
@@ -1038,12 +1074,24 @@ __device__ __forceinline__ void bootstrap64d(const PT& P, const bce_gate_desc g,
     const double2* __restrict__ tw = P.tw64d;
     // LDS mirror of the first 1024 twiddle entries (8-wave kernel only: 16 KiB of the 20 KiB left next to the polynomials)
     double2* twl = reinterpret_cast<double2*>(av + ((P.n + 1 + 3) & ~3u));
-    if constexpr (SPLIT)
+    // W1 (folded key): all N twiddles in those 16 KiB as plain doubles (see Tw); -DBCE_TWQ keeps the (w, w / Q) pairs (A/B runs)
+#ifdef BCE_TWQ
+    constexpr bool W1 = false;
+#else
+    constexpr bool W1 = FOLD && SPLIT;
+#endif
+    typedef TwSel<W1> TS;
+    typedef typename TS::T TV;
+    double* twl1 = reinterpret_cast<double*>(twl);
+    if constexpr (W1) {
+        for (u32 i = tid_o; i < (u32)N; i += T) twl1[i] = tw[i].x;
+    } else if constexpr (SPLIT) {
         for (u32 i = tid_o; i < 1024u; i += T) twl[i] = tw[i];
-    const Tw twa{tw, twl};
-
+    }
     const u32 tid = tid_o, lane = tid & 63, wave = tid >> 6;
     const double Q = P.Qd, invQ = P.invQd;
+    const Tw twa{tw, twl, twl1, invQ};
+
     const u32 q = P.q, qm = q - 1, n = P.n;
     {
         const u32* in0 = P.pool + (size_t)(g.in0 + soff) * P.pool_stride;
@@ -1082,10 +1130,14 @@ __device__ __forceinline__ void bootstrap64d(const PT& P, const bce_gate_desc g,
     __syncthreads();
     if (wave == 0) ntt_forward_wave<LOGN>(acc + NP, Tw{tw, nullptr}, lane, Q);
     __syncthreads();
-    for (u32 j = tid; j < (u32)N; j += T) acc[NP + phys(j)] = modred(acc[NP + phys(j)], invQ, Q);
+    const double2 ninv = make_double2(P.Ninvd, P.Ninvd_q);
+    // KN (folded key): the evaluation-form accumulator lives scaled by N^-1 -- rows l >= 1 of the key carry the factor, rows 0, 1
+    // multiply the (scaled) accumulator itself -- so the un-normalised inverse transform of a step returns the coefficients
+    constexpr bool KN = FOLD && (BCE_KEY_NINV != 0);
+    for (u32 j = tid; j < (u32)N; j += T)
+        acc[NP + phys(j)] = KN ? modmul_q(acc[NP + phys(j)], ninv.x, ninv.y, Q) : modred(acc[NP + phys(j)], invQ, Q);
     __syncthreads();
 
-    const double2 ninv = make_double2(P.Ninvd, P.Ninvd_q);
     constexpr size_t rgsw = (size_t)R * 2 * N;
     const double* __restrict__ bsk = reinterpret_cast<const double*>(P.bsk64);
     // SignedDigitDecompose: representative of the reference (canonical x, `x < Q/2 ? x : x - Q`), closed-form digits
@@ -1155,19 +1207,19 @@ __device__ __forceinline__ void bootstrap64d(const PT& P, const bce_gate_desc g,
             const u32 c = wave >> 2, t = tid_v & 255u;
             double x[8];
             // exchange buffers live in dct rows 0..3 (dead until the digits are written)
-            split_inverse11(cur + c * NP, dct + (XA + c) * NP, dct + (XB + c) * NP, twa, t, Q, x);
+            split_inverse11<W1>(cur + c * NP, dct + (XA + c) * NP, dct + (XB + c) * NP, twa, t, Q, x);
             block_sync_lds();  // every thread has read its pass-3 inputs: the digit rows may be overwritten
             // digits, then the first three FORWARD stages (bits 10, 9, 8 = this thread's register index) on each digit
             // in registers: the forward transform below is left with bits 7..0 (two passes)
             double u[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                double d = modmul_q(x[r], ninv.x, ninv.y, Q);
+                double d = KN ? modred(x[r], invQ, Q) : modmul_q(x[r], ninv.x, ninv.y, Q);
                 d = d > dhi ? d - Q : d;
                 d = d < dlo ? d + Q : d;
                 u[r] = d + doff;
             }
-            const double2 w10 = twl[1], w9a = twl[2], w9b = twl[3];
+            const TV w10 = TS::lds(twa, 1), w9a = TS::lds(twa, 2), w9b = TS::lds(twa, 3);
 #pragma unroll
             for (u32 l = 0; l < (u32)DG; ++l) {
                 double v[8];
@@ -1180,20 +1232,20 @@ __device__ __forceinline__ void bootstrap64d(const PT& P, const bce_gate_desc g,
                 if (FOLD && l == 0) continue;   // digit 0 only advances the running quotient
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {  // bit 10: (r, r+4), twiddle tw[1]
-                    const double T = modmul_q(v[r + 4], w10.x, w10.y, Q);
+                    const double T = tmul_digit(v[r + 4], w10, twa, Q);   // |digit| <= B / 2 = 2^12 (gBits = 13: checked by the host)
                     v[r + 4] = v[r] - T; v[r] = v[r] + T;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {  // bit 9: (r, r+2), r in {0,1,4,5}, twiddle tw[2 + (r >> 2)]
                     const int r = (k >> 1) * 4 + (k & 1);
-                    const double2 w = (k >> 1) ? w9b : w9a;
-                    const double T = modmul_q(v[r + 2], w.x, w.y, Q);
+                    const TV w = (k >> 1) ? w9b : w9a;
+                    const double T = tmul(v[r + 2], w, twa, Q);
                     v[r + 2] = v[r] - T; v[r] = v[r] + T;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {  // bit 8: (2k, 2k+1), twiddle tw[4 + k]
-                    const double2 w = twl[4 + k];
-                    const double T = modmul_q(v[2 * k + 1], w.x, w.y, Q);
+                    const TV w = TS::lds(twa, 4 + k);
+                    const double T = tmul(v[2 * k + 1], w, twa, Q);
                     v[2 * k + 1] = v[2 * k] - T; v[2 * k] = v[2 * k] + T;
                 }
 #pragma unroll
@@ -1224,11 +1276,11 @@ __device__ __forceinline__ void bootstrap64d(const PT& P, const bce_gate_desc g,
         if constexpr (FOLD && W16) {
             // rows 2..5 as sixteen quarter-transforms, one per wave (four per SIMD), no barrier inside the phase (eight
             // half-transforms on waves 0..7 with waves 8..15 idle: 21.0 vs 20.2 ms per launch, profiles/r02_fold_quarters_ab.log)
-            forward_quarter<LOGN>(dct + (2 + (wave & 3u)) * NP, wave >> 2, twa, lane_v, Q);
+            forward_quarter<LOGN, W1>(dct + (2 + (wave & 3u)) * NP, wave >> 2, twa, lane_v, Q);
         } else if constexpr (FOLD) {
             // eight waves: rows 2..5 as eight half-transforms, waves w and w + 4 share a row (and a SIMD); two quarter-
             // transforms per wave instead measure the same
-            forward_half<LOGN>(dct + (2 + (wave & 3u)) * NP, twa, (wave >> 2) * 64u + lane_v, Q);
+            forward_half<LOGN, W1>(dct + (2 + (wave & 3u)) * NP, twa, (wave >> 2) * 64u + lane_v, Q);
         } else if constexpr (W16) {
             forward_phase_halves<LOGN>(dct, NP, twa, wave, lane_v, Q);
         } else if constexpr (SPLIT) {
@@ -1307,12 +1359,12 @@ __device__ __forceinline__ void bootstrap64d(const PT& P, const bce_gate_desc g,
     } else if constexpr (SPLIT) {
         const u32 c = wave >> 2, t = tid & 255u;
         double x[8];
-        split_inverse11(cur + c * NP, dct + (XA + c) * NP, dct + (XB + c) * NP, twa, t, Q, x);
+        split_inverse11<W1>(cur + c * NP, dct + (XA + c) * NP, dct + (XB + c) * NP, twa, t, Q, x);
         u64* out = acc_out + ((size_t)boot * 2 + c) * N;
         u64* coef = reinterpret_cast<u64*>(acc);   // FUSE: [2][N] u64 in the accumulator's own rows (dead: `cur` was read by pass 0)
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const double y = modmul_q(x[r], ninv.x, ninv.y, Q);
+            const double y = KN ? modred(x[r], invQ, Q) : modmul_q(x[r], ninv.x, ninv.y, Q);
             const double v = y < 0.0 ? y + Q : y;
             const double hi = floor(v * (1.0 / 4294967296.0));
             const u64 wv = ((u64)(u32)hi << 32) | (u64)(u32)fma(-hi, 4294967296.0, v);
