@@ -126,8 +126,9 @@ int bce_circuit_check_relevel(bce_circuit*);
  * and one Clock() is ONE persistent kernel launch in which a finished bootstrap releases its consumers on the device:
  * the ready-gate rule of Circuit::_ManageGates (src/circuit.cpp:575-683) applied per gate, not per frontier, with no
  * kernel boundary between dependent gates.  Same ciphertexts in every register.  XOR temporaries get slots of their
- * own, so call it before SetInput.  Ignored (the bootstrap-depth schedule runs instead) in verify mode, under gate
- * sharding and for parameter classes without the persistent kernel: bce_circuit_dataflow_active tells. */
+ * own, so call it before SetInput.  Ignored under gate sharding and for parameter classes without the persistent kernel
+ * (the bootstrap-depth step schedule runs instead); verify mode carries a plaintext pass and therefore runs the reference's
+ * gate-level rounds whatever schedule was chosen.  bce_circuit_dataflow_active tells. */
 int bce_circuit_set_dataflow(bce_circuit*, int on);
 int bce_circuit_dataflow_active(const bce_circuit*);   /* 1 if the next encrypted Clock() takes the dataflow path */
 /* Opt-in for the bootstrap-depth schedule (set_relevel): its launches are captured once into a hipGraph and every

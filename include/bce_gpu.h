@@ -230,9 +230,10 @@ int bce_dag_debug_block_task(bce_dag*, uint32_t t);
 /* ---- measurement ------------------------------------------------------- */
 int bce_timing_reset(bce_ctx*);
 int bce_timing_get(bce_ctx*, bce_timing* out); /* synchronizes */
-/* on (default): HIP events around every blind-rotation / tail launch feed the *_ms fields.  off: launches and bootstraps are
- * still counted, the *_ms fields stop growing, and no event packet sits between dependent kernels (15 us per dependent step on
- * the device timeline -- what matters when a step is one bootstrap latency).  bce_dag_run / bce_plan_run keep their one pair. */
+/* on (default): every blind-rotation / tail launch carries a start and a stop timestamp ON ITS OWN DISPATCH (hipExtLaunchKernel
+ * events: the *_ms fields are the kernels' own durations, nothing is recorded between dependent kernels; 11 us per dependent step
+ * on the device timeline against 15.6 us with events recorded around the launches, as rounds 1-2 did).  off: launches and
+ * bootstraps are still counted, the *_ms fields stop growing, plain launches.  bce_dag_run / bce_plan_run keep their one pair. */
 int bce_timing_set_events(bce_ctx*, int on);
 /* algorithmic bytes one gate-bootstrap reads at the widths this engine ships
  * (SURVEY.md 8(d) formula with w_bsk, w_ks, w_ct of this build) */

@@ -591,8 +591,14 @@ int launch_bootstraps(bce_ctx* c, const bce_gate_desc* dd, u32 n, u32 instances,
     // the timestamps ride on the kernels' own dispatches (LaunchEvents): no event packet between dependent launches
     LaunchEvents le0{};
     if (events) { e0 = get_events(c, 0); le0 = LaunchEvents{e0.a, e0.b}; }
-    if (c->is64) HIP_TRY(c, launch_blind_rotate64(c->P, dd, n, instances, slot_stride, static_cast<u64*>(d_acc), c->stream, d_lweN, d_ks, &tail_fused, le0));
-    else HIP_TRY(c, launch_blind_rotate(c->P, dd, n, instances, slot_stride, static_cast<u32*>(d_acc), c->stream, &kid, d_lweN, d_ks, &tail_fused, le0));
+    {   // a launch that fails hands its event pair back (it would otherwise be neither pending nor free)
+        const hipError_t e = c->is64 ? launch_blind_rotate64(c->P, dd, n, instances, slot_stride, static_cast<u64*>(d_acc), c->stream, d_lweN, d_ks, &tail_fused, le0)
+                                     : launch_blind_rotate(c->P, dd, n, instances, slot_stride, static_cast<u32*>(d_acc), c->stream, &kid, d_lweN, d_ks, &tail_fused, le0);
+        if (e != hipSuccess) {
+            if (events) c->free_events.push_back(e0);
+            HIP_TRY(c, e);
+        }
+    }
     if (events) {
         e0.kind = kid;
         c->pending.push_back(e0);
@@ -619,7 +625,11 @@ int launch_bootstraps(bce_ctx* c, const bce_gate_desc* dd, u32 n, u32 instances,
                 c->tail_cap = cap;
             }
         }
-        HIP_TRY(c, launch_tail(c->P, dd, n, instances, slot_stride, d_acc, d_partial ? d_partial : c->d_tail_partial, d_lweN, d_ks, c->stream, le1));
+        const hipError_t e = launch_tail(c->P, dd, n, instances, slot_stride, d_acc, d_partial ? d_partial : c->d_tail_partial, d_lweN, d_ks, c->stream, le1);
+        if (e != hipSuccess) {
+            if (events) c->free_events.push_back(e1);
+            HIP_TRY(c, e);
+        }
         if (events) c->pending.push_back(e1);
     } else if (timed) {
         c->timing.fused_tail_launches += 1;

@@ -141,8 +141,8 @@ hipError_t launch_bootstrap_dag64(const DevParams& P, const DevParams* d_P, cons
 struct LaunchEvents {
     hipEvent_t start = nullptr, stop = nullptr;
 };
-// kern(args...) with the events attached (or a plain launch when both are null); args are converted to the kernel's own
-// parameter types first
+// kern(args...) through hipExtLaunchKernel with the two events attached to the DISPATCH (its start / stop timestamps; either
+// may be null: the launch is then simply untimed on that side); args are converted to the kernel's own parameter types first
 template <typename... KA, typename... A>
 inline hipError_t launch_with_events(void (*kern)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t s, LaunchEvents ev, A... args) {
     static_assert(sizeof...(KA) == sizeof...(A), "argument count");
