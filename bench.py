@@ -535,8 +535,8 @@ def main():
                     return d, n
             return None, None
         cfg5 = args.paramset == "STD192" and args.method == "AP"
-        traffic, traffic_file = newest(["r03_pmc_traffic.json", "r02_pmc_traffic.json"]) if default_cmd else (None, None)
-        valu, valu_file = newest(["r03_valu_model.json", "r02_valu_model.json"]) if not cfg5 else newest(["r03_cfg5_roofline.json", "r02_cfg5_roofline.json"])
+        traffic, traffic_file = newest(["r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"]) if default_cmd else (None, None)
+        valu, valu_file = newest(["r04_valu_model.json", "r03_valu_model.json", "r02_valu_model.json"]) if not cfg5 else newest(["r04_cfg5_roofline.json", "r03_cfg5_roofline.json", "r02_cfg5_roofline.json"])
         traffic_bytes = traffic["hbm_bytes_per_launch"] if traffic and traffic.get("bench_kernel") == dom["kernel"] else None
         compulsory = (bsk_once + (parts["ct"] + (parts["ksk"] if fused else 0)) * per_launch) if bsk_once is not None else br_bytes * per_launch
         hbm = {

@@ -122,6 +122,7 @@ def test_in_library_rccl_allgather_world_of_one():
     uid = cc.rccl_unique_id()
     assert len(uid) == 128
     cc.rccl_init(uid, 0, 1)
+    assert cc.rccl_comm_info() == {"ranks": 1, "rank": 0, "device": 0}          # ncclCommCount / UserRank / CuDevice of that communicator
     W = cc.n + 1
     send = torch.zeros(4 * W, dtype=torch.int32, device="cuda:0")
     recv = torch.zeros(4 * W, dtype=torch.int32, device="cuda:0")
