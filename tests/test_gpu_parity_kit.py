@@ -100,6 +100,27 @@ def test_oracle_made_vector_file_replays_word_for_word(bce, orc, tmp_path, ps, m
     o.close()
 
 
+@pytest.mark.parametrize("method", ["GINX", "AP"])
+def test_vector_file_of_a_37_bit_modulus_context(bce, orc, tmp_path, method):
+    """The kit on the 64-bit-modulus path (STD192's ring: N = 2048, 37-bit Q, three digits base 2^13; small n so that the
+    oracle writes the file in seconds): compare.py builds the context from the parameters in the files, the gates run on the
+    folded fp64 kernels (N^-1 in the key, 8-byte twiddles), the tail probes on the 64-bit tail kernels, the NTT probe on
+    the 64-bit transform."""
+    L = orc.lib()
+    N = 2048
+    Q = L.bo_previous_prime(L.bo_first_prime(37, 2 * N), 2 * N)
+    params = (16, N, 512, Q, 1 << 15, 32, 1 << 13, 23)
+    o = orc.Oracle(method=getattr(orc, method), custom=params)
+    o.keygen(4242)
+    keys, vecs = str(tmp_path / "keys.bce"), str(tmp_path / "vectors.bgv")
+    write_keyfile(keys, o, with_z=False)
+    kit.write_gatevec(vecs, o.params["method"], file_params(o), oracle_vectors(orc, o, gates=6, seed=9))
+    sink = Sink()
+    assert kit.compare(keys, vecs, out=sink) == 0, sink.text()
+    assert "RESULT: every record identical" in sink.text() and "Q %d" % Q in sink.text()
+    o.close()
+
+
 def test_a_single_flipped_word_fails_and_is_localised(bce, orc, tmp_path):
     o = orc.Oracle(orc.TOY, orc.GINX)
     o.keygen(778)
