@@ -119,7 +119,11 @@ int bce_import_keys(bce_ctx*, const int32_t* s, const int32_t* z, const uint64_t
  * the bit-reversed order of OpenFHE's Cooley-Tukey forward transform (transformnat-impl.h) for psi = the minimal
  * primitive 2N-th root of unity mod Q (bce_get_params: BCE_P_psi; 455622 / 341565 / 13167220 for the tabulated sets) --
  * the engine's own order, so an OpenFHE-side dump needs no SetFormat(COEFFICIENT) pass over the key (12.9 GB for
- * STD192 / AP) and the import needs no transform.  bce_export_bsk_eval is its inverse. */
+ * STD192 / AP) and the import needs no transform.  bce_export_bsk_eval is its inverse.
+ * PARITY UNPINNED: that this IS OpenFHE's order is recalled, not checked against OpenFHE (absent here) -- it is pinned only
+ * against the oracle's own transform.  The gate-vector file of tools/openfhe_export carries NTT records (a polynomial before
+ * and after OpenFHE's SetFormat(EVALUATION)) and compare.py checks them with bce_debug_ntt: use this entry point with
+ * OpenFHE-made keys only after that check has passed; the coefficient-form import does not depend on the order. */
 int bce_import_keys_eval(bce_ctx*, const int32_t* s, const int32_t* z, const uint64_t* bsk_eval, uint64_t bsk_words,
                          const uint32_t* ksk, uint64_t ksk_words);
 int bce_export_bsk_eval(bce_ctx*, uint64_t* bsk_eval);
