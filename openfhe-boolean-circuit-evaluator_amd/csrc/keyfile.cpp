@@ -81,6 +81,24 @@ int bce_import_keys_file(bce_ctx* c, const char* path) {
     if (h.bsk_format > BCE_KEYFILE_BSK_EVALUATION) return bce_set_error(c, BCE_ERR_UNSUPPORTED, "key file: unknown bootstrapping-key representation");
     for (uint64_t k = 0; h.has_z && k < h.N; ++k)
         if (z[k] < -1 || z[k] > 1) return bce_set_error(c, BCE_ERR_ARG, "key file: ring secret entries must be -1, 0 or 1");
+    // optional trailer: (coefficient, evaluation) pairs of the producer.  An evaluation-form key is only usable if the
+    // producer's evaluation order is this engine's: check it where it can be checked instead of trusting the header
+    if (m.len >= need + 16 && std::memcmp(base + need, BCE_KEYFILE_NTTCHECK_MAGIC, 8) == 0) {
+        uint32_t count = 0;
+        std::memcpy(&count, base + need + 8, 4);
+        if (count > 64 || m.len < need + 16 + (size_t)count * 2 * h.N * 8) return bce_set_error(c, BCE_ERR_ARG, "key file: truncated transform-check trailer");
+        const char* pairs = base + need + 16;     // byte offsets: the trailer need not be 8-byte aligned in the file
+        const size_t poly = (size_t)h.N * 8;
+        std::vector<uint64_t> t(h.N);
+        for (uint32_t k = 0; k < count && h.bsk_format == BCE_KEYFILE_BSK_EVALUATION; ++k) {
+            std::memcpy(t.data(), pairs + (size_t)k * 2 * poly, poly);
+            const int rc = bce_debug_ntt(c, t.data(), 1, 0);
+            if (rc) return rc;
+            if (std::memcmp(t.data(), pairs + ((size_t)k * 2 + 1) * poly, poly) != 0)
+                return bce_set_error(c, BCE_ERR_UNSUPPORTED, "key file: the producer's EVALUATION representation is not this engine's (transform-check pair differs): "
+                                                              "export the bootstrapping key in coefficient form (bsk_format 0)");
+        }
+    }
     return h.bsk_format == BCE_KEYFILE_BSK_EVALUATION ? bce_import_keys_eval(c, s, z, bsk, h.bsk_words, ksk, h.ksk_words)
                                                       : bce_import_keys(c, s, z, bsk, h.bsk_words, ksk, h.ksk_words);
 }

@@ -206,4 +206,19 @@ def test_evaluation_form_key_file_and_vectors(bce, orc, tmp_path):
     kit.write_gatevec(vecs, p["method"], file_params(o), oracle_vectors(orc, o, gates=6))
     sink = Sink()
     assert kit.compare(keys, vecs, out=sink) == 0, sink.text()
+    # the transform-check trailer (what export_keys.cpp appends in evaluation mode): matching pairs are accepted, a producer
+    # whose evaluation order differs is refused at import with a message that names the way out
+    body = open(keys, "rb").read()
+    rng = np.random.default_rng(2)
+    coef = rng.integers(0, p["Q"], o.N, dtype=np.uint64)
+    good = body + b"BCENTTCK" + struct.pack("<II", 1, 0) + coef.astype("<u8").tobytes() + o.ntt_forward(coef).astype("<u8").tobytes()
+    open(keys, "wb").write(good)
+    c = bce.BinFHEContext(bce.TOY, bce.GINX)
+    c.import_keys_file(keys)
+    wrong = np.roll(o.ntt_forward(coef), 1)                       # "another order"
+    open(keys, "wb").write(body + b"BCENTTCK" + struct.pack("<II", 1, 0) + coef.astype("<u8").tobytes() + wrong.astype("<u8").tobytes())
+    with pytest.raises(bce.BceError) as e:
+        c.import_keys_file(keys)
+    assert "EVALUATION representation is not this engine's" in str(e.value)
+    c.close()
     o.close()

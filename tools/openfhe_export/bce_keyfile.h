@@ -27,6 +27,11 @@
  *                         row r of an RGSW ciphertext = RLWE pair (a_r, a_r * z + e_r) with the gadget power
  *                         baseG^(r/2) * message added to column r mod 2
  *           4*ksk_words   key-switching key, u32 words: [i < N][v < baseKS][j < dKS][a_0 .. a_{n-1}, b]  mod qKS
+ *           optional trailer (recommended with bsk_format = 1): magic "BCENTTCK", u32 count, u32 0, then count pairs
+ *                         (coef[N], eval[N]) of u64 words -- one polynomial in COEFFICIENT representation and the same
+ *                         polynomial as the producer holds it in EVALUATION representation.  The importer transforms coef
+ *                         with its own forward transform and REFUSES an evaluation-form key whose pairs do not match: the
+ *                         producer's evaluation order is then not the engine's, and the key must be exported with bsk_format = 0.
  */
 #ifndef BCE_KEYFILE_H
 #define BCE_KEYFILE_H
@@ -36,6 +41,7 @@
 #define BCE_KEYFILE_VERSION 1u
 #define BCE_KEYFILE_BSK_COEFFICIENT 0u
 #define BCE_KEYFILE_BSK_EVALUATION 1u
+#define BCE_KEYFILE_NTTCHECK_MAGIC "BCENTTCK"
 
 #pragma pack(push, 1)
 typedef struct bce_keyfile_header {

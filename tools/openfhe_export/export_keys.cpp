@@ -256,6 +256,24 @@ int main(int argc, char** argv) {
                     put(f, row.data(), row.size() * sizeof(uint32_t));
                 }
     }
+    if (g_evaluation_form) {
+        // two (coefficient, evaluation) pairs: the importer checks that its own forward transform reproduces OpenFHE's order
+        // before it accepts a key dumped without SetFormat (bce_keyfile.h, trailer)
+        put(f, BCE_KEYFILE_NTTCHECK_MAGIC, 8);
+        const uint32_t count[2] = {2, 0};
+        put(f, count, sizeof count);
+        std::mt19937_64 rng(0x77C0FFEEull);
+        const auto poly_params = rgsw->GetPolyParams();
+        for (uint32_t t = 0; t < 2; ++t) {
+            NativePoly p(poly_params, Format::COEFFICIENT, true);
+            std::vector<uint64_t> coef(N), eval(N);
+            for (uint32_t k = 0; k < N; ++k) { coef[k] = rng() % Q; p[k] = NativeInteger(coef[k]); }
+            p.SetFormat(Format::EVALUATION);
+            for (uint32_t k = 0; k < N; ++k) eval[k] = p[k].ConvertToInt();
+            put(f, coef.data(), N * sizeof(uint64_t));
+            put(f, eval.data(), N * sizeof(uint64_t));
+        }
+    }
     std::fclose(f);
 
     int rest = 4;
