@@ -1197,12 +1197,37 @@ __device__ __forceinline__ void bootstrap64d(const PT& P, const bce_gate_desc g,
         };
         if constexpr (!EARLY && NPRE >= 1) request(std::integral_constant<u32, 0>{});
         if constexpr (!EARLY && NPRE >= 2) request(std::integral_constant<u32, 1>{});
+        // the first three FORWARD stages (bits 10, 9, 8 = the register index) on one digit polynomial's eight coefficients of a thread
+        auto three_stages = [&](double (&v)[8]) {
+            const TV w10 = TS::lds(twa, 1), w9a = TS::lds(twa, 2), w9b = TS::lds(twa, 3);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // bit 10: (r, r+4), twiddle tw[1]
+                const double T = tmul_digit(v[r + 4], w10, twa, Q);   // |digit| <= B / 2 = 2^12 (gBits = 13: checked by the host)
+                v[r + 4] = v[r] - T; v[r] = v[r] + T;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // bit 9: (r, r+2), r in {0,1,4,5}, twiddle tw[2 + (r >> 2)]
+                const int r = (k >> 1) * 4 + (k & 1);
+                const TV w = (k >> 1) ? w9b : w9a;
+                const double T = tmul(v[r + 2], w, twa, Q);
+                v[r + 2] = v[r] - T; v[r] = v[r] + T;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // bit 8: (2k, 2k+1), twiddle tw[4 + k]
+                const TV w = TS::lds(twa, 4 + k);
+                const double T = tmul(v[2 * k + 1], w, twa, Q);
+                v[2 * k + 1] = v[2 * k] - T; v[2 * k] = v[2 * k] + T;
+            }
+        };
         if (W16 && tid_v >= 512u) {
-            // waves 8..15 have no share of the inverse transforms: they only keep the barrier count (and, EARLY, pull
-            // their key rows while their registers are free)
+            // waves 8..15 have no share of the inverse transforms: they keep the barrier count (and, EARLY, pull their key rows
+            // while their registers are free)
             if constexpr (EARLY) for_each_index(request, std::make_integer_sequence<u32, ITEMS>{});
 #pragma unroll
             for (int b = 0; b < INV_BARRIERS + 1; ++b) block_sync_lds();
+            // (round 4, rejected: handing the top digit's raw coefficients to these waves through its digit rows so that they
+            // run its three in-register stages -- one more barrier, 12 of 24 butterflies off waves 0..7 -- is 2.3 % SLOWER per
+            // 1,024-bootstrap launch, profiles/r04_cfg5_offload_ab.log)
         } else if constexpr (SPLIT) {
             const u32 c = wave >> 2, t = tid_v & 255u;
             double x[8];
@@ -1219,35 +1244,20 @@ __device__ __forceinline__ void bootstrap64d(const PT& P, const bce_gate_desc g,
                 d = d < dlo ? d + Q : d;
                 u[r] = d + doff;
             }
-            const TV w10 = TS::lds(twa, 1), w9a = TS::lds(twa, 2), w9b = TS::lds(twa, 3);
-#pragma unroll
-            for (u32 l = 0; l < (u32)DG; ++l) {
-                double v[8];
+            auto next_digit = [&](double (&v)[8]) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const double fl = floor(u[r] * invB);
                     v[r] = fma(-fl, Bd, u[r]) - halfB;  // digit in [-B/2, B/2)
                     u[r] = fl;
                 }
+            };
+#pragma unroll
+            for (u32 l = 0; l < (u32)DG; ++l) {
+                double v[8];
+                next_digit(v);
                 if (FOLD && l == 0) continue;   // digit 0 only advances the running quotient
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {  // bit 10: (r, r+4), twiddle tw[1]
-                    const double T = tmul_digit(v[r + 4], w10, twa, Q);   // |digit| <= B / 2 = 2^12 (gBits = 13: checked by the host)
-                    v[r + 4] = v[r] - T; v[r] = v[r] + T;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {  // bit 9: (r, r+2), r in {0,1,4,5}, twiddle tw[2 + (r >> 2)]
-                    const int r = (k >> 1) * 4 + (k & 1);
-                    const TV w = (k >> 1) ? w9b : w9a;
-                    const double T = tmul(v[r + 2], w, twa, Q);
-                    v[r + 2] = v[r] - T; v[r] = v[r] + T;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {  // bit 8: (2k, 2k+1), twiddle tw[4 + k]
-                    const TV w = TS::lds(twa, 4 + k);
-                    const double T = tmul(v[2 * k + 1], w, twa, Q);
-                    v[2 * k + 1] = v[2 * k] - T; v[2 * k] = v[2 * k] + T;
-                }
+                three_stages(v);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) dct[(2 * l + c) * NP + phys(((u32)r << 8) | t)] = v[r];
             }
