@@ -194,6 +194,8 @@ def main():
     ap.add_argument("--fresh-inputs", action="store_true",
                     help="encrypt inputs FRESH instead of the reference-shaped BOOTSTRAPPED default (profiled runs: the refresh launches of "
                          "SetInput use the same kernel and would mix into its rocprofv3 statistics; they are setup, outside the timed region)")
+    ap.add_argument("--no-dataflow-leg", action="store_true",
+                    help="N = 1, step schedule: skip the secondary run of the same workload as ONE persistent launch (bce_dag_run)")
     ap.add_argument("--no-block-latency", action="store_true",
                     help="skip the K = 1 single-block leg (profiled runs: keeps the kernel statistics to the timed workload)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -255,7 +257,7 @@ def main():
     K_total = args.instances
     first_run = {"t": None}
 
-    def run_mode(shard_mode, steps, warmup, relevel, exchange="callback", K_run=None):
+    def run_mode(shard_mode, steps, warmup, relevel, exchange="callback", K_run=None, schedule=None):
         """One timed run.  shard_mode 0 (instances): every rank evaluates ITS OWN K input blocks with its own
         circuit object -- independent units, no data-path collective (only the barrier / reductions of this
         script).  shard_mode 1 (gates): ONE set of K blocks, every level's gates split over the ranks by bootstrap
@@ -272,9 +274,10 @@ def main():
         if gates:
             cc.set_encrypt_seed(0x0FE5EED)   # every rank must encrypt IDENTICAL input ciphertexts
         circ.setRelevel(bool(relevel))
-        if args.schedule == "dataflow" and not gates:
+        schedule = schedule or args.schedule
+        if schedule == "dataflow" and not gates:
             circ.setDataflow(True)
-        if args.schedule == "graph" and not gates:
+        if schedule == "graph" and not gates:
             circ.setGraph(True)
         info = circ.info()
         circ.setInstances(K_run)
@@ -389,7 +392,7 @@ def main():
                 "K_run": K_run, "shard_mode": shard_mode if world > 1 else 0, "per_rank_ms_per_step": [round(x / steps * 1e3, 3) for x in per_rank_s],
                 "in_library_comm": rccl_info,
                 "launches_per_step": st["sublaunches"], "dataflow": df_active, "identity": identity,
-                "dag_last_run": cc.dag_last_run() if (args.schedule == "dataflow" and not gates) else None,
+                "dag_last_run": cc.dag_last_run() if (schedule == "dataflow" and not gates) else None,
                 "exchanges_per_step": st["exchanges"], "exchanged_cts_per_step": xcts, "steps": steps, "t_ready": t_ready, "t_begin": t_begin,
                 "exchange_path": ("in-library ncclAllGather on the engine stream (no host sync)" if (xch is not None and xch.in_library) else
                                   ("torch.distributed all_gather_into_tensor callback after a stream sync" + (" [in-library RCCL unavailable: %s]" % xch.why if xch is not None and xch.why not in ("", "not requested") else "")) if xch is not None else "none")}
@@ -740,6 +743,17 @@ def main():
                 "rccl_ranks": (G2["in_library_comm"] or {}).get("ranks"), "communicator": G2["in_library_comm"],
                 "counted_by": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the library's own communicator (rank 0's view)",
                 "ciphertext_identity": G2["identity"]})
+        if world == 1 and args.schedule == "steps" and R["relevel"] and not args.no_dataflow_leg and cc.dag_supported():
+            # the same workload as ONE persistent launch with device-side ready queues (identical registers); secondary: the
+            # headline keeps the per-step launches its per-launch roofline evidence is collected on
+            try:
+                D = run_mode(0, 1, 1, True, schedule="dataflow")
+                out["dataflow"] = {"what": "the same K blocks, whole bootstrap DAG in one persistent launch per evaluation (bce_dag_run, Circuit.setDataflow)",
+                                   "value": D["total_boot"] / D["elapsed"], "unit": "gate-bootstraps/s", "ms_per_step": D["elapsed"] / D["steps"] * 1e3,
+                                   "steps": D["steps"], "warmup": 1, "launches_per_step": D["launches_per_step"], "active": bool(D["dataflow"]),
+                                   "outputs_verified": bool(D["verified"]), "scheduler": D["dag_last_run"]}
+            except Exception as e:
+                out["dataflow"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(path, args.paramset, args.method, args.cpu_seconds)
         with emit_lock:

@@ -18,7 +18,7 @@ export TMPDIR=/tmp
 cd /tmp
 # --fresh-inputs: the refresh bootstraps of SetInput (reference-shaped BOOTSTRAPPED default) run on the same kernel as the
 # timed steps; without them the kernel statistics and the per-launch counters below hold the 416 timed launches only
-BENCH1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-block-latency --fresh-inputs"
+BENCH1="python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-block-latency --no-dataflow-leg --fresh-inputs"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH1 > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof_stats.err"
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/bench_kernel_stats.csv"
 head -5 "$OUT/bench_kernel_stats.csv"
