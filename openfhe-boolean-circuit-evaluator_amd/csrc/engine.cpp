@@ -95,6 +95,7 @@ struct bce_ctx {
     uint2* d_twf = nullptr;
     u32* d_psi = nullptr;
     u32* d_psi_r2 = nullptr;
+    u32* d_xcd_gate = nullptr;
     void* d_bsk = nullptr;       // u32 words (Q < 2^28) or u64 words (is64)
     ulonglong2* d_tw64 = nullptr;
     double2* d_tw64d = nullptr;   // (w, w / Q) for the double-precision formulation
@@ -314,6 +315,13 @@ int build_ctx(u32 n, u32 N, u64 q, u64 Q, u64 qKS, u32 baseKS, u32 baseG, u32 ba
     P.tw_f = c->d_twf;
     P.psi_tab = c->d_psi;
     P.psi_tab_r2 = c->d_psi_r2;
+    P.xcd_gate = nullptr;
+    P.xcd_gate_ticks = 10000;   // 100 us
+    if (const char* e = std::getenv("BCE_XCD_GATE"); !c->is64 && !(e && e[0] == '0')) {   // on by default (32-bit path); BCE_XCD_GATE=0: A/B runs
+        if (hipMalloc(&c->d_xcd_gate, 16 * 32 * sizeof(u32)) != hipSuccess) { g_create_error = "hipMalloc(xcd gate) failed"; return BCE_ERR_HIP; }
+        P.xcd_gate = c->d_xcd_gate;
+        if (const char* t = std::getenv("BCE_XCD_GATE_US")) P.xcd_gate_ticks = (u32)std::atoi(t) * 100u;
+    }
     P.is64 = c->is64 ? 1 : 0;
     P.Q64 = Q;
     P.Q8p1_64 = Q / 8 + 1;
@@ -749,7 +757,7 @@ void bce_ctx_destroy(bce_ctx* c) {
     }
     hipFree(c->d_io); if (c->h_io) hipHostFree(c->h_io);
     hipFree(c->d_P); if (c->h_dag_status) hipHostFree(c->h_dag_status); if (c->h_dag_stage) hipHostFree(c->h_dag_stage);
-    hipFree(c->d_twf); hipFree(c->d_psi); hipFree(c->d_psi_r2); hipFree(c->d_tw64); hipFree(c->d_tw64d); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc); hipFree(c->d_tail_partial);
+    hipFree(c->d_twf); hipFree(c->d_psi); hipFree(c->d_psi_r2); hipFree(c->d_xcd_gate); hipFree(c->d_tw64); hipFree(c->d_tw64d); hipFree(c->d_bsk); hipFree(c->d_ksk); hipFree(c->d_pool); hipFree(c->d_acc); hipFree(c->d_tail_partial);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }

@@ -1104,6 +1104,24 @@ __device__ __forceinline__ void lat_bootstrap(const PT& P, const bce_gate_desc g
     const u32 lane = tid & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 Q = P.Q, q = P.q, qm = q - 1, n = P.n;
+    if constexpr (WPS >= 4 && !PERSIST) {
+        // XCD start gate of a multi-round launch (round 4): the workgroups that take over an XCD's slots as the previous round
+        // retires start their bootstraps together, so that they walk the key in lock-step (one L2 fill per row and XCD) like
+        // the first round does.  Without it the rounds of a launch drift apart and re-fetch the key from the Infinity Cache:
+        // FETCH_SIZE of a 6,144-bootstrap launch 45-54 GB -> 19.3 GB (= 6 x the 3.2 GB of a two-round launch), launch time
+        // -0.8 % (profiles/r04_gate_ab.log).  Wave 0 waits, wave-uniform, at most xcd_gate_ticks; the others meet it at the
+        // prologue's barrier.
+        if (P.xcd_gate != nullptr && wave == 0) {
+            const u32 xcc = __builtin_amdgcn_s_getreg((31u << 11) | 20u) & 15u;
+            u32* const gate = P.xcd_gate + 32u * xcc;
+            const u32 slots = 2u * (P.cu_count >> 3);                       // resident workgroups of one XCD
+            const u32 mine = (gridDim.x + 7u - xcc) >> 3;                   // this launch's workgroups on this XCD (round-robin dispatch)
+            const u32 t = u_add(gate, 1u);
+            const u32 full = (t / slots + 1u) * slots, target = full < mine ? full : mine;
+            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            while (u_ld(gate) < target && __builtin_amdgcn_s_memrealtime() - t0 < P.xcd_gate_ticks) __builtin_amdgcn_s_sleep(8);
+        }
+    }
     bootstrap_prologue<LOGN, true, T>(P, g, soff, twf, acc, av, tid, lane, wave);
 
     const u32 c = wave >> 2;  // this wave's inverse-transform group = accumulator component
@@ -1458,8 +1476,11 @@ hipError_t launch_blind_rotate(const DevParams& P, const bce_gate_desc* d, u32 n
         if (tail_fused) *tail_fused = fuse;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lat);
         if (e != hipSuccess) return e;
-        if (ev.start || ev.stop) return launch_with_events(lk, grid, block, lds_lat, s, ev, P, d, n_desc, slot_stride, acc_out, fuse ? dbg_lweN : nullptr, fuse ? dbg_ks : nullptr);
-        hipLaunchKernelGGL(lk, grid, block, lds_lat, s, P, d, n_desc, slot_stride, acc_out, fuse ? dbg_lweN : nullptr, fuse ? dbg_ks : nullptr);
+        DevParams Pl = P;
+        if (x1 || grid.x <= 2 * P.cu_count) Pl.xcd_gate = nullptr;            // one round: every workgroup starts at once anyway
+        if (Pl.xcd_gate && (e = hipMemsetAsync(Pl.xcd_gate, 0, 16 * 32 * sizeof(u32), s)) != hipSuccess) return e;
+        if (ev.start || ev.stop) return launch_with_events(lk, grid, block, lds_lat, s, ev, Pl, d, n_desc, slot_stride, acc_out, fuse ? dbg_lweN : nullptr, fuse ? dbg_ks : nullptr);
+        hipLaunchKernelGGL(lk, grid, block, lds_lat, s, Pl, d, n_desc, slot_stride, acc_out, fuse ? dbg_lweN : nullptr, fuse ? dbg_ks : nullptr);
         return hipGetLastError();
     }
     switch (P.logN) {

@@ -43,6 +43,9 @@ struct DevParams {
     u32 variant;           // blind-rotation kernel choice: 0 automatic; 1 one-wave-per-transform kernel; 2 / 3 split-
                            // transform kernel forced to its 256- / 128-register build (development knob BCE_VARIANT)
     u32 cu_count;          // compute units of the device (automatic choice: a launch of <= cu_count workgroups)
+    u32* xcd_gate;         // [16 XCC ids][32 words] arrival counters of the launch's workgroups per XCD, or null: multi-round launches of
+                           // the split-transform kernel start their workgroups in per-XCD cohorts (round 4; BCE_XCD_GATE=0 disables)
+    u32 xcd_gate_ticks;    // longest wait at that gate (100 MHz ticks)
     u32 fuse_tail;         // 1: saturated launches of the split-transform kernel run the tail in their epilogue (BCE_FUSE_TAIL=0 disables)
     u32 fold_ninv;         // 1 (folded fp64 kernels, kernels64.hip): rows l >= 1 of the key are also multiplied by N^-1 and the
                            // evaluation-form accumulator is kept scaled by N^-1, so that the un-normalised inverse transform yields
