@@ -419,7 +419,6 @@ def main():
         ver = lib_ver = None
         try:
             ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
-            lib_ver = int(bce.lib().bce_rccl_version()) or None      # ncclGetVersion of the librccl the engine dlopen()s
         except Exception:
             pass
         return {"backend": "nccl (= RCCL on ROCm)" if backend == "nccl" else backend + " (rehearsal: not RCCL)",
@@ -743,6 +742,11 @@ def main():
                 "rccl_ranks": (G2["in_library_comm"] or {}).get("ranks"), "communicator": G2["in_library_comm"],
                 "counted_by": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the library's own communicator (rank 0's view)",
                 "ciphertext_identity": G2["identity"]})
+        if world > 1 and "rccl" in out:
+            try:      # asked LAST: the engine dlopen()s the system's librccl for it, next to the one torch brought along
+                out["rccl"]["rccl_version_seen_by_the_library"] = int(bce.lib().bce_rccl_version()) or None
+            except Exception:
+                pass
         if world == 1 and args.schedule == "steps" and R["relevel"] and not args.no_dataflow_leg and cc.dag_supported():
             # the same workload as ONE persistent launch with device-side ready queues (identical registers); secondary: the
             # headline keeps the per-step launches its per-launch roofline evidence is collected on
