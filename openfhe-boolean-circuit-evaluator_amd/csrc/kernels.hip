@@ -1114,7 +1114,7 @@ __device__ __forceinline__ void lat_bootstrap(const PT& P, const bce_gate_desc g
         if (P.xcd_gate != nullptr && wave == 0) {
             const u32 xcc = __builtin_amdgcn_s_getreg((31u << 11) | 20u) & 15u;
             u32* const gate = P.xcd_gate + 32u * xcc;
-            const u32 slots = 2u * (P.cu_count >> 3);                       // resident workgroups of one XCD
+            const u32 slots = max(2u, 2u * (P.cu_count >> 3));              // resident workgroups of one XCD
             const u32 mine = (gridDim.x + 7u - xcc) >> 3;                   // this launch's workgroups on this XCD (round-robin dispatch)
             const u32 t = u_add(gate, 1u);
             const u32 full = (t / slots + 1u) * slots, target = full < mine ? full : mine;
