@@ -702,6 +702,38 @@ def test_std128_saturated_launch_of_distinct_gates_equals_oracle(std128, bce):
         assert o.decrypt(got[i]) == want
 
 
+def test_multi_round_launches_with_and_without_the_xcd_start_gate(bce, orc, monkeypatch):
+    """Launches of more than one round of workgroups start their workgroups in per-XCD cohorts (DevParams::xcd_gate; wave 0
+    waits, bounded, for the 64 workgroups that share an XCD's slots).  A launch of 1,100 bootstraps -- two full rounds and
+    a partial third, so that the last cohort of every XCD is short and leaves through its count or its time-out -- must leave
+    the ciphertexts a gate-less context (BCE_XCD_GATE=0) leaves, and the oracle's on a sample."""
+    o = orc.Oracle(orc.STD128_OPT, orc.GINX)
+    o.keygen(77)
+    nb = 1100
+    rng = np.random.default_rng(8)
+    bits = rng.integers(0, 2, size=2 * nb).astype(np.uint8)
+    descs = bce.make_descs([(int(rng.choice([bce.AND, bce.OR, bce.NAND, bce.NOR])), 2 * i, 2 * i + 1, 2 * nb + i, int(rng.integers(0, 2)), 0) for i in range(nb)])
+    outs = []
+    for gate in ("1", "0"):
+        monkeypatch.setenv("BCE_XCD_GATE", gate)
+        c = bce.BinFHEContext(bce.STD128_OPT, bce.GINX)
+        c.KeyGen(77)
+        c.set_encrypt_seed(5)
+        c.pool_reserve(3 * nb)
+        c.Encrypt(bits, np.arange(2 * nb, dtype=np.uint32), enc_index_base=0)
+        c.EvalGates(descs)
+        c.EvalGates(descs)                           # a second launch re-arms the counters
+        outs.append((c.lwe_read(np.arange(0, 2 * nb, dtype=np.uint32)), c.lwe_read(np.arange(2 * nb, 3 * nb, dtype=np.uint32))))
+        c.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    ins, got = outs[0]
+    for i in (0, 511, 512, 1023, 1024, nb - 1):      # first / last workgroup of every round
+        d = descs[i]
+        a = o.eval_not(ins[2 * i]) if d.neg0 else ins[2 * i]
+        assert np.array_equal(got[i], o.eval_bingate(d.op, a, ins[2 * i + 1])), i
+    o.close()
+
+
 @pytest.mark.parametrize("ps,fwd", [("STD128", 6), ("STD192_OPT", 4), ("STD128_APOPT", 6), ("MEDIUM", 6), ("STD256", 8), ("STD256_OPT", 8)])
 def test_other_parameter_sets_of_the_table_same_seed_keys(bce, orc, ps, fwd):
     """The remaining rows of OpenFHE's parameter table that the kernels cover, GINX: STD128 (n = 512) runs the folded
